@@ -1,0 +1,168 @@
+/*
+ * yy_engine.h -- C ABI of libyy_hip.so, the MI355X (gfx950) Yin-Yang self-play hot path.
+ *
+ * The reference (Arash-san/YinYang-Game-AlphaZero) is pure Python and has no FFI: the drop-in
+ * boundary is its Python class API.  This header is the C-ABI a maintainer would bind with ctypes
+ * from those classes (INTEGRATION.md shows the stubs); every entry point cites the reference
+ * interface it replaces as path:line under the reference root.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; ALL data pointers are DEVICE pointers (HBM) unless the
+ *     parameter is documented as host; no torch types.
+ *   - every function returns an int status (YY_OK or a negative YY_E_*); yy_last_error() gives a
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no call synchronises unless documented ("sync").
+ *   - boards are int8 [G,R,C] row-major, 0 empty / +1 black / -1 white
+ *     (src/yin_yang/yin_yang_logic.py:8-18); players are int8 +1 / -1; an action is x*C+y
+ *     (src/yin_yang/yin_yang_game.py:180-186).  1 <= R,C <= 16 and R*C <= 192.
+ */
+#ifndef YY_ENGINE_H
+#define YY_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YY_OK 0
+#define YY_E_INVALID (-1)     /* null pointer, non-positive size, bad enum */
+#define YY_E_UNSUPPORTED (-2) /* board larger than 16x16 / 192 cells */
+#define YY_E_NOMEM (-3)       /* hipMalloc failed */
+#define YY_E_HIP (-4)         /* HIP runtime error (message in yy_last_error) */
+#define YY_E_STATE (-5)       /* call order violation (e.g. expand before select) */
+#define YY_E_ARENA (-6)       /* a game's tree arena overflowed (reported by yy_mcts_status) */
+
+/* rule / semantics flags */
+#define YY_FLAG_ROWCOL 1u  /* also enforce the browser-only full-row/column rule
+                              (src/gui/static/js/yin_yang_game.js:338-384). Default off: the
+                              Python rules have no such rule. */
+#define YY_FLAG_ALIASED 2u /* MCTS shares ONE board per game through the whole tree and mutates
+                              it, exactly like the reference (yin_yang_game.py:52-58 +
+                              ai/mcts.py:385-397).  Default (flag clear) = "copied": every
+                              expanded node owns its board. */
+
+typedef void *yy_stream_t;
+
+const char *yy_last_error(void);
+int yy_version(void);
+
+/* ------------------------------------------------------------------ stateless rules kernels */
+
+/* YinYangGame.getValidMoves(board, player)  (yin_yang_game.py:60-78 over
+ * yin_yang_logic.py:31-128).  out_mask: uint8 [G,A], 1 = legal.  players: int8 [G]. */
+int yy_rules_valid_mask(const int8_t *boards, const int8_t *players, int G, int R, int C,
+                        uint32_t flags, uint8_t *out_mask, yy_stream_t stream);
+
+/* YinYangGame.getNextState(board, player, action)  (yin_yang_game.py:39-58,
+ * yin_yang_logic.py:24-29): place iff legal IN PLACE, then players[g] = -players[g] regardless.
+ * placed: uint8 [G] (may be NULL). */
+int yy_rules_step(int8_t *boards, int8_t *players, const int32_t *actions, int G, int R, int C,
+                  uint32_t flags, uint8_t *placed, yy_stream_t stream);
+
+/* YinYangGame.getGameEnded(board, player)  (yin_yang_game.py:80-110): out float64 [G] holding
+ * exactly the reference's values 0, +1, -1, 0.0001.  counts: int32 [G,2] = count_pieces()
+ * (yin_yang_logic.py:130-134), may be NULL. */
+int yy_rules_game_ended(const int8_t *boards, const int8_t *players, int G, int R, int C,
+                        uint32_t flags, double *out, int32_t *counts, yy_stream_t stream);
+
+/* YinYangNeuralNetwork.board_to_input(board)  (ai/neural_network.py:156-196):
+ * out float32 [G,5,R,C] = [empty, black, white, row fill, column fill]. */
+int yy_encode_planes(const int8_t *boards, int G, int R, int C, float *out, yy_stream_t stream);
+
+/* Native packed form of the same rules: one game per lane on bitboards.
+ * black/white: uint64 [NW][G] (word-major SoA, NW = ceil(R*C/64), bit a = cell a);
+ * mask_p1/mask_m1: uint64 [NW][G] legal masks for +1 / -1; result: int8 [G] game-ended code from
+ * BLACK's (+1) point of view: 0 ongoing, +1, -1, 2 = draw.  Any output may be NULL. */
+int yy_rules_mask_terminal_bb(const uint64_t *black, const uint64_t *white, int G, int R, int C,
+                              uint32_t flags, uint64_t *mask_p1, uint64_t *mask_m1,
+                              int8_t *result, yy_stream_t stream);
+
+/* int8 boards <-> packed bitboards (layout as above). */
+int yy_pack_boards(const int8_t *boards, int G, int R, int C, uint64_t *black, uint64_t *white,
+                   yy_stream_t stream);
+int yy_unpack_boards(const uint64_t *black, const uint64_t *white, int G, int R, int C,
+                     int8_t *boards, yy_stream_t stream);
+
+/* ------------------------------------------------------------------ batched MCTS context
+ * One context = G concurrent games searched in lockstep; replaces Node + MCTS.search/_simulate
+ * (ai/mcts.py:28-225, 275-414).  Per lockstep step:
+ *     yy_mcts_select        -> leaf planes for the evaluator   (mcts.py:356-362, 385-397)
+ *     <policy/value CNN on planes, caller's business>
+ *     yy_mcts_expand_backup <- policy, value                   (mcts.py:50-91, 406-412)
+ * or the fused yy_mcts_step (= expand_backup of the previous leaves + select of the next). */
+
+typedef struct yy_mcts_config {
+    int32_t G;                 /* concurrent games */
+    int32_t R, C;              /* board */
+    int32_t max_sims;          /* largest num_simulations a search will run (sizes the arenas) */
+    float cpuct;               /* mcts.py:231 cpuct */
+    uint32_t flags;            /* YY_FLAG_* */
+    int64_t edges_per_game;    /* 0 = worst case (max_sims+2)*A */
+    int64_t nodes_per_game;    /* 0 = max_sims+2 */
+} yy_mcts_config;
+
+typedef struct yy_mcts yy_mcts; /* opaque */
+
+/* sync. Allocates the arenas in HBM on the current device. */
+int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out);
+int yy_mcts_destroy(yy_mcts *ctx);
+/* bytes of HBM held by the context (host out) */
+int yy_mcts_memory_bytes(const yy_mcts *ctx, uint64_t *out);
+
+/* MCTS.search prologue (mcts.py:288-295): fresh root per game from boards int8 [G,R,C] and
+ * root_players int8 [G]; active uint8 [G] (NULL = all active; inactive games are skipped by every
+ * later call).  Writes the root planes float32 [G,5,R,C] for evaluator call #0. */
+int yy_mcts_begin(yy_mcts *ctx, const int8_t *boards, const int8_t *root_players,
+                  const uint8_t *active, float *planes_out, yy_stream_t stream);
+
+/* Root expansion (mcts.py:297-317).  policy float32 [G,A] = softmax output of call #0 (the value
+ * is discarded by the reference).  noise: NULL, or float64 [G,A] holding each game's Dirichlet
+ * draw scattered to its legal action indices; priors become
+ * f32( f64(f32(1-eps) * p) + eps*noise )  exactly as mcts.py:310-312 evaluates under numpy 2. */
+int yy_mcts_expand_root(yy_mcts *ctx, const float *policy, const double *noise, double eps,
+                        yy_stream_t stream);
+
+/* Selection + leaf state (mcts.py:356-399 up to the predict call): PUCT descent in float32
+ * (mcts.py:97-145), place-if-legal, terminal test and legal mask of the new position, and the 5
+ * input planes written to row g of planes_out float32 [G,5,R,C].  needs_eval uint8 [G] = 1 when
+ * row g must be evaluated (0: terminal leaf revisited, or inactive). */
+int yy_mcts_select(yy_mcts *ctx, float *planes_out, uint8_t *needs_eval, yy_stream_t stream);
+
+/* Expansion + backup (mcts.py:50-91, 147-156, 406-412) for the leaves chosen by the last select.
+ * policy float32 [G,A], value float32 [G] (rows with needs_eval == 0 are ignored). */
+int yy_mcts_expand_backup(yy_mcts *ctx, const float *policy, const float *value,
+                          yy_stream_t stream);
+
+/* Fused: expand_backup(policy, value) then select(planes_out, needs_eval) in ONE launch. */
+int yy_mcts_step(yy_mcts *ctx, const float *policy, const float *value, float *planes_out,
+                 uint8_t *needs_eval, yy_stream_t stream);
+
+/* Root child visit counts int32 [G,A] (Node.get_children_visit_counts, mcts.py:168-181);
+ * optional per-child value_sum float32 [G,A] and prior float32 [G,A] (NULL to skip). */
+int yy_mcts_root_counts(yy_mcts *ctx, int32_t *counts, float *child_w, float *child_p,
+                        yy_stream_t stream);
+
+/* Node.get_children_distribution(T) for T == 1 (counts/sum, uniform 1/A when all zero) or T == 0
+ * (uniform over the arg-max set) in float64 [G,A]  (mcts.py:183-215). */
+int yy_mcts_root_policy(yy_mcts *ctx, int temperature_is_zero, double *pi, yy_stream_t stream);
+
+/* root.visits int32 [G] and root.value_sum float64 [G] (mcts.py:39-40). */
+int yy_mcts_root_stats(yy_mcts *ctx, int32_t *visits, double *value_sum, yy_stream_t stream);
+
+/* The board each game's root refers to after the search, int8 [G,R,C]: unchanged in copied mode,
+ * the mutated caller board in aliased mode. */
+int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
+
+/* sync. Host outputs: number of games whose arena overflowed (they stop searching), and
+ * counters[8] = {evaluator rows requested, selection levels walked, children scanned during
+ * selection, children created, terminal revisits, nodes created, 0, 0} accumulated since create
+ * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
+int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
+int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YY_ENGINE_H */

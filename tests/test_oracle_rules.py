@@ -1,0 +1,53 @@
+"""The CPU oracle (oracle/yy_oracle.c) against the golden vectors captured from the imported
+reference (tests/golden/make_golden.py): G1 rules and G2 planes.  Bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RULES = sorted(glob.glob(os.path.join(GOLDEN, "rules_*.npz")))
+PLANES = sorted(glob.glob(os.path.join(GOLDEN, "planes_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(RULES) >= 3 and len(PLANES) >= 3
+
+
+@pytest.mark.parametrize("path", RULES, ids=[os.path.basename(p) for p in RULES])
+def test_rules_against_reference(path):
+    z = np.load(path)
+    b = z["boards"]
+    assert np.array_equal(O.valid_mask(b, 1), z["mask_p1"])
+    assert np.array_equal(O.valid_mask(b, -1), z["mask_m1"])
+    assert np.array_equal(O.game_ended(b, 1), z["ended_p1"])
+    assert np.array_equal(O.game_ended(b, -1), z["ended_m1"])
+    assert np.array_equal((b == 1).sum((1, 2)), z["counts"][:, 0])
+    assert np.array_equal((b == -1).sum((1, 2)), z["counts"][:, 1])
+    nb, npl, placed = O.next_state(b, z["players"], z["step_action"])
+    assert np.array_equal(nb, z["step_board"])
+    assert np.array_equal(npl, z["step_player"])
+    assert np.array_equal(placed, z["step_placed"])
+
+
+@pytest.mark.parametrize("path", PLANES, ids=[os.path.basename(p) for p in PLANES])
+def test_planes_against_reference(path):
+    z = np.load(path)
+    got = O.encode_planes(z["boards"])
+    assert got.dtype == np.float32
+    assert np.array_equal(got, z["planes"])
+
+
+def test_hash_eval_matches_generator():
+    """The C hash evaluator equals the numpy one used when the goldens were made."""
+    from hash_eval import hash_eval_np
+    rng = np.random.default_rng(0)
+    for (R, C) in ((3, 3), (6, 6), (8, 8), (12, 12), (5, 7)):
+        for pb, vb in ((10, 11), (2, 2), (6, 4)):
+            b = rng.integers(-1, 2, size=(R, C)).astype(np.int8)
+            p0, v0 = O.hash_eval(b, pb, vb)
+            p1, v1 = hash_eval_np(b, pb, vb)
+            assert np.array_equal(p0, p1) and v0 == v1

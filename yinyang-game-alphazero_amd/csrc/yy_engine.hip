@@ -1,0 +1,1042 @@
+// yy_engine.hip -- HIP kernels + C ABI (include/yy_engine.h) of the Yin-Yang self-play hot path
+// for MI355X (gfx950, wave64).  Written for CDNA4 only.
+//
+// Execution model
+//   * tree kernels: ONE GAME PER WAVEFRONT (block = 64 threads, blockIdx.x = game).  Lane l owns
+//     board cell(s) l, l+64, l+128 and child edge(s) l, l+64, ... of the node being scanned, so a
+//     node's children are read with one coalesced 16-B-per-lane load, the PUCT arg-max is a
+//     wave reduction, the legal mask -> child list compaction is a ballot/mbcnt prefix sum, and
+//     the 5 input planes are written as coalesced rows.  Bitboards are wave-uniform (SGPRs).
+//   * stateless rules kernels: ONE GAME PER LANE on the same bitboard code, boards staged through
+//     LDS so the int8 [G,R,C] tensors are read/written coalesced.
+//   * blockIdx -> game is fixed, and blocks are dealt round-robin over the 8 XCDs, so a game's
+//     arena stays in the same XCD's L2 from launch to launch (speed only, never correctness).
+//
+// HBM layout (all per context, game-major):
+//   edges  uint4 [G][edge_cap]   {prior f32, visits i32, value_sum f32, child(24b)|action<<24}
+//   nodes  uint4 [G][node_cap]   {first_edge, k | flags<<16 | player<<24, terminal value f32, -}
+//   nboard u64   [G][node_cap][2*NW]   (copied mode only) black words then white words
+//   gboard u64   [G][2*NW]       root board (copied) / THE shared board (aliased)
+//   path   i32   [G][path_cap]   edge indices chosen by the last selection
+//   state  GameState [G]         counters, root statistics, the pending leaf record
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/yy_engine.h"
+#include "yy_bitboard.h"
+
+#define YY_VERSION 100
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char *fmt, const char *a = "", const char *b = "") {
+    snprintf(g_err, sizeof g_err, fmt, a, b);
+    return code;
+}
+#define HIP_TRY(x)                                                                    \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) return set_err(YY_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *yy_last_error(void) { return g_err; }
+extern "C" int yy_version(void) { return YY_VERSION; }
+
+static int check_geo(int G, int R, int C) {
+    if (G <= 0 || R <= 0 || C <= 0) return set_err(YY_E_INVALID, "non-positive size%s%s");
+    if (R > YY_MAX_DIM || C > YY_MAX_DIM || R * C > 64 * YY_MAX_NW)
+        return set_err(YY_E_UNSUPPORTED, "board larger than 16x16 / 192 cells%s%s");
+    return YY_OK;
+}
+
+// ------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int rfl(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+}
+__device__ __forceinline__ float rflf(float v) { return __uint_as_float(rfl(__float_as_uint(v))); }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// number of set bits of m below this lane's position
+__device__ __forceinline__ int mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NW> __device__ __forceinline__ BB<NW> bb_uniform_load(const uint64_t *p) {
+    BB<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r.w[i] = rfl64(p[i]);
+    return r;
+}
+template <int NW> __device__ __forceinline__ void bb_store_lane0(uint64_t *p, BB<NW> b) {
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; i++) p[i] = b.w[i];
+    }
+}
+
+// wave-cooperative: int8 board (cell per lane) -> uniform bitboards via ballot
+template <int NW>
+__device__ __forceinline__ void board_to_bb(const int8_t *b, int A, BB<NW> &black, BB<NW> &white) {
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        int cell = j * 64 + lane_id();
+        int v = (cell < A) ? (int)b[cell] : 0;
+        black.w[j] = __ballot(v == 1);
+        white.w[j] = __ballot(v == -1);
+    }
+}
+template <int NW>
+__device__ __forceinline__ void bb_to_board(int8_t *b, int A, BB<NW> black, BB<NW> white) {
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        int cell = j * 64 + lane_id();
+        if (cell < A)
+            b[cell] = ((black.w[j] >> lane_id()) & 1) ? 1 : (((white.w[j] >> lane_id()) & 1) ? -1 : 0);
+    }
+}
+
+// row r of `occ` as the low C bits (C <= 16; may straddle a word boundary)
+template <int NW> __device__ __forceinline__ uint32_t bb_row_bits(BB<NW> occ, int r, int C) {
+    int s = r * C, w = s >> 6, o = s & 63;
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        if (i == w) lo = occ.w[i];
+        if (i == w + 1) hi = occ.w[i];
+    }
+    uint64_t v = lo >> o;
+    if (o) v |= hi << (64 - o);
+    return (uint32_t)v & ((1u << C) - 1u);
+}
+
+// wave-cooperative board_to_input (neural_network.py:156-196): lane = cell, coalesced rows
+template <int NW>
+__device__ __forceinline__ void write_planes(float *out, const YYGeo &geo, BB<NW> black, BB<NW> white) {
+    const int A = geo.A, C = geo.C;
+    BB<NW> occ = black | white;
+    BB<NW> col0 = bb_load<NW>(geo.col0);
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        int cell = j * 64 + lane_id();
+        if (cell < A) {
+            int r = cell / C, c = cell - r * C;
+            bool bk = (black.w[j] >> lane_id()) & 1, wh = (white.w[j] >> lane_id()) & 1;
+            int rowk = __popc(bb_row_bits(occ, r, C));
+            int colk = bb_popc(occ & bb_shl(col0, c));
+            out[cell] = (!bk && !wh) ? 1.0f : 0.0f;
+            out[A + cell] = bk ? 1.0f : 0.0f;
+            out[2 * A + cell] = wh ? 1.0f : 0.0f;
+            out[3 * A + cell] = geo.rowfill[rowk];
+            out[4 * A + cell] = geo.colfill[colk];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- stateless kernels
+// One game per lane; the block's boards (64 games x A bytes, contiguous in HBM) are staged through
+// LDS so global traffic is coalesced.
+#define RULES_BLOCK 64
+
+template <int NW>
+__device__ __forceinline__ void lds_board_to_bb(const int8_t *lb, int A, BB<NW> &black, BB<NW> &white) {
+    black = bb_zero<NW>();
+    white = bb_zero<NW>();
+    for (int a = 0; a < A; a++) {
+        int v = lb[a];
+        if (v == 1) black.w[a >> 6] |= 1ull << (a & 63);
+        if (v == -1) white.w[a >> 6] |= 1ull << (a & 63);
+    }
+}
+
+// stage this block's boards global -> LDS (coalesced bytes)
+__device__ __forceinline__ void stage_in(int8_t *lds, const int8_t *boards, int g0, int ng, int A) {
+    const int n = ng * A;
+    const int8_t *src = boards + (size_t)g0 * A;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+}
+
+template <int NW>
+__global__ void __launch_bounds__(RULES_BLOCK) k_valid_mask(const int8_t *boards, const int8_t *players,
+                                                            int G, YYGeo geo, uint8_t *out) {
+    __shared__ int8_t lds[RULES_BLOCK * 64 * YY_MAX_NW];
+    const int A = geo.A, g0 = blockIdx.x * RULES_BLOCK;
+    const int ng = min(RULES_BLOCK, G - g0);
+    stage_in(lds, boards, g0, ng, A);
+    const int g = g0 + threadIdx.x;
+    BB<NW> mask = bb_zero<NW>();
+    if (threadIdx.x < ng) {
+        GeoBB<NW> gb = geo_bb<NW>(geo);
+        BB<NW> black, white;
+        lds_board_to_bb<NW>(lds + threadIdx.x * A, A, black, white);
+        bool pre = bb_pre2x2(black, white, gb);
+        mask = (players[g] == 1) ? bb_legal(black, white, pre, geo, gb) : bb_legal(white, black, pre, geo, gb);
+    }
+    __syncthreads();
+    if (threadIdx.x < ng)
+        for (int a = 0; a < A; a++) lds[threadIdx.x * A + a] = (int8_t)bb_test(mask, a);
+    __syncthreads();
+    uint8_t *dst = out + (size_t)g0 * A;
+    for (int i = threadIdx.x; i < ng * A; i += blockDim.x) dst[i] = (uint8_t)lds[i];
+}
+
+template <int NW>
+__global__ void __launch_bounds__(RULES_BLOCK) k_step(int8_t *boards, int8_t *players, const int32_t *actions,
+                                                      int G, YYGeo geo, uint8_t *placed) {
+    const int g = blockIdx.x * RULES_BLOCK + threadIdx.x;
+    if (g >= G) return;
+    const int A = geo.A;
+    GeoBB<NW> gb = geo_bb<NW>(geo);
+    BB<NW> black = bb_zero<NW>(), white = bb_zero<NW>();
+    int8_t *b = boards + (size_t)g * A;
+    for (int a = 0; a < A; a++) {
+        int v = b[a];
+        if (v == 1) black.w[a >> 6] |= 1ull << (a & 63);
+        if (v == -1) white.w[a >> 6] |= 1ull << (a & 63);
+    }
+    const int p = players[g], a = actions[g];
+    bool ok = false;
+    if (a >= 0 && a < A) {  // yin_yang_logic.py:34 bounds check
+        bool pre = bb_pre2x2(black, white, gb);
+        BB<NW> m = (p == 1) ? bb_legal(black, white, pre, geo, gb) : bb_legal(white, black, pre, geo, gb);
+        ok = bb_test(m, a);
+    }
+    if (ok) b[a] = (p == 1) ? 1 : -1;  // yin_yang_game.py:55-56
+    players[g] = (int8_t)-p;           // yin_yang_game.py:58, regardless
+    if (placed) placed[g] = ok;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(RULES_BLOCK) k_game_ended(const int8_t *boards, const int8_t *players, int G,
+                                                            YYGeo geo, double *out, int32_t *counts) {
+    __shared__ int8_t lds[RULES_BLOCK * 64 * YY_MAX_NW];
+    const int A = geo.A, g0 = blockIdx.x * RULES_BLOCK;
+    const int ng = min(RULES_BLOCK, G - g0);
+    stage_in(lds, boards, g0, ng, A);
+    if (threadIdx.x >= ng) return;
+    const int g = g0 + threadIdx.x;
+    GeoBB<NW> gb = geo_bb<NW>(geo);
+    BB<NW> black, white;
+    lds_board_to_bb<NW>(lds + threadIdx.x * A, A, black, white);
+    bool pre = bb_pre2x2(black, white, gb);
+    BB<NW> mb = bb_legal(black, white, pre, geo, gb), mw = bb_legal(white, black, pre, geo, gb);
+    int res = bb_result_black(black, white, mb, mw);
+    double v = 0.0;
+    if (res == 2) v = 0.0001;                                   // yin_yang_game.py:107
+    else if (res != 0) v = (players[g] == 1) ? (double)res : (double)-res;
+    out[g] = v;
+    if (counts) {
+        counts[2 * g] = bb_popc(black);
+        counts[2 * g + 1] = bb_popc(white);
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64) k_encode(const int8_t *boards, int G, YYGeo geo, float *out) {
+    const int g = blockIdx.x;
+    BB<NW> black, white;
+    board_to_bb<NW>(boards + (size_t)g * geo.A, geo.A, black, white);
+    write_planes<NW>(out + (size_t)g * 5 * geo.A, geo, black, white);
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64) k_pack(const int8_t *boards, int G, YYGeo geo, uint64_t *black, uint64_t *white) {
+    const int g = blockIdx.x;
+    BB<NW> b, w;
+    board_to_bb<NW>(boards + (size_t)g * geo.A, geo.A, b, w);
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            black[(size_t)j * G + g] = b.w[j];
+            white[(size_t)j * G + g] = w.w[j];
+        }
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64) k_unpack(const uint64_t *black, const uint64_t *white, int G, YYGeo geo,
+                                               int8_t *boards) {
+    const int g = blockIdx.x;
+    BB<NW> b, w;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        b.w[j] = rfl64(black[(size_t)j * G + g]);
+        w.w[j] = rfl64(white[(size_t)j * G + g]);
+    }
+    bb_to_board<NW>(boards + (size_t)g * geo.A, geo.A, b, w);
+}
+
+// packed rules: one game per lane, SoA word-major bitboards -> fully coalesced 8-B loads/stores
+template <int NW>
+__global__ void __launch_bounds__(256) k_mask_terminal_bb(const uint64_t *black, const uint64_t *white, int G,
+                                                          YYGeo geo, uint64_t *m1, uint64_t *m2, int8_t *result) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+        GeoBB<NW> gb = geo_bb<NW>(geo);
+        BB<NW> b, w;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            b.w[j] = black[(size_t)j * G + g];
+            w.w[j] = white[(size_t)j * G + g];
+        }
+        bool pre = bb_pre2x2(b, w, gb);
+        BB<NW> mb = bb_legal(b, w, pre, geo, gb), mw = bb_legal(w, b, pre, geo, gb);
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            if (m1) m1[(size_t)j * G + g] = mb.w[j];
+            if (m2) m2[(size_t)j * G + g] = mw.w[j];
+        }
+        if (result) result[g] = (int8_t)bb_result_black(b, w, mb, mw);
+    }
+}
+
+#define DISPATCH_NW(NWv, ...)                                  \
+    switch (NWv) {                                             \
+        case 1: { constexpr int NW = 1; __VA_ARGS__; } break;  \
+        case 2: { constexpr int NW = 2; __VA_ARGS__; } break;  \
+        default: { constexpr int NW = 3; __VA_ARGS__; } break; \
+    }
+
+extern "C" int yy_rules_valid_mask(const int8_t *boards, const int8_t *players, int G, int R, int C, uint32_t flags,
+                                   uint8_t *out, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !players || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, flags);
+    dim3 grid((G + RULES_BLOCK - 1) / RULES_BLOCK);
+    DISPATCH_NW(geo.NW, k_valid_mask<NW><<<grid, dim3(RULES_BLOCK), 0, (hipStream_t)s>>>(boards,
+                                            players, G, geo, out));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_rules_step(int8_t *boards, int8_t *players, const int32_t *actions, int G, int R, int C,
+                             uint32_t flags, uint8_t *placed, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !players || !actions) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, flags);
+    dim3 grid((G + RULES_BLOCK - 1) / RULES_BLOCK);
+    DISPATCH_NW(geo.NW, k_step<NW><<<grid, dim3(RULES_BLOCK), 0, (hipStream_t)s>>>(boards, players,
+                                            actions, G, geo, placed));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_rules_game_ended(const int8_t *boards, const int8_t *players, int G, int R, int C, uint32_t flags,
+                                   double *out, int32_t *counts, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !players || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, flags);
+    dim3 grid((G + RULES_BLOCK - 1) / RULES_BLOCK);
+    DISPATCH_NW(geo.NW, k_game_ended<NW><<<grid, dim3(RULES_BLOCK), 0, (hipStream_t)s>>>(boards,
+                                            players, G, geo, out, counts));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_encode_planes(const int8_t *boards, int G, int R, int C, float *out, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, 0);
+    DISPATCH_NW(geo.NW, k_encode<NW><<<dim3(G), dim3(64), 0, (hipStream_t)s>>>(boards, G, geo, out));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_pack_boards(const int8_t *boards, int G, int R, int C, uint64_t *black, uint64_t *white,
+                              yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !black || !white) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, 0);
+    DISPATCH_NW(geo.NW,
+                k_pack<NW><<<dim3(G), dim3(64), 0, (hipStream_t)s>>>(boards, G, geo, black, white));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_unpack_boards(const uint64_t *black, const uint64_t *white, int G, int R, int C, int8_t *boards,
+                                yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!boards || !black || !white) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, 0);
+    DISPATCH_NW(geo.NW,
+                k_unpack<NW><<<dim3(G), dim3(64), 0, (hipStream_t)s>>>(black, white, G, geo, boards));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_rules_mask_terminal_bb(const uint64_t *black, const uint64_t *white, int G, int R, int C,
+                                         uint32_t flags, uint64_t *m1, uint64_t *m2, int8_t *result, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (int e = check_geo(G, R, C)) return e;
+    if (!black || !white) return set_err(YY_E_INVALID, "null pointer%s%s");
+    YYGeo geo;
+    yy_make_geo(&geo, R, C, flags);
+    int blocks = (G + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    DISPATCH_NW(geo.NW, k_mask_terminal_bb<NW><<<dim3(blocks), dim3(256), 0, (hipStream_t)s>>>(black,
+                                            white, G, geo, m1, m2, result));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+// =============================================================================== MCTS context
+enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5 };
+#define CHILD_NONE 0x00FFFFFFu
+#define NF_TERMINAL 1u
+
+struct GameState {
+    int32_t n_nodes, n_edges;
+    int32_t root_N;
+    float root_W;
+    double root_W_py;       // root.value_sum while it is still a python float (terminal root only)
+    int32_t path_len;       // edges on the selected path == depth of the leaf
+    int32_t leaf_node;      // node record of the leaf when it already has one, else -1
+    float leaf_tv;          // terminal value of a freshly evaluated leaf (f32 of 1 / -1 / 1e-4)
+    int8_t root_player;
+    uint8_t active, err, root_w_is_py;
+    uint8_t leaf_kind;
+    int8_t leaf_player;
+    uint8_t leaf_terminal, pad0;
+    uint64_t leaf_board[2 * YY_MAX_NW];
+    uint64_t leaf_mask[YY_MAX_NW];
+    uint64_t ctr[6];        // evals, levels, children scanned, children created, terminal revisits, nodes
+};
+
+struct yy_mcts {
+    yy_mcts_config cfg;
+    YYGeo geo;
+    int64_t node_cap, edge_cap, path_cap;
+    uint4 *edges, *nodes;
+    uint64_t *nboard, *gboard;
+    int32_t *path;
+    GameState *state;
+    float *sqrt_tab;
+    uint64_t *scratch;      // [8] counters + overflow count
+    uint64_t bytes;
+    int pending;            // 1 = a select is pending an expand_backup
+};
+
+struct MctsDev {  // by-value kernel argument
+    YYGeo geo;
+    int32_t G;
+    uint32_t aliased;
+    float cpuct;
+    double eps;
+    int64_t node_cap, edge_cap, path_cap;
+    uint4 *edges, *nodes;
+    uint64_t *nboard, *gboard;
+    int32_t *path;
+    GameState *state;
+    const float *sqrt_tab;
+    int32_t sqrt_n;
+};
+
+static MctsDev make_dev(const yy_mcts *c) {
+    MctsDev d;
+    d.geo = c->geo;
+    d.G = c->cfg.G;
+    d.aliased = (c->cfg.flags & YY_FLAG_ALIASED) ? 1u : 0u;
+    d.cpuct = c->cfg.cpuct;
+    d.eps = 0.0;
+    d.node_cap = c->node_cap;
+    d.edge_cap = c->edge_cap;
+    d.path_cap = c->path_cap;
+    d.edges = c->edges;
+    d.nodes = c->nodes;
+    d.nboard = c->nboard;
+    d.gboard = c->gboard;
+    d.path = c->path;
+    d.state = c->state;
+    d.sqrt_tab = c->sqrt_tab;
+    d.sqrt_n = c->cfg.max_sims + 2;
+    return d;
+}
+
+__device__ __forceinline__ uint32_t node_pack(int k, uint32_t flags, int player) {
+    return (uint32_t)k | (flags << 16) | ((uint32_t)(player & 0xFF) << 24);
+}
+__device__ __forceinline__ int node_k(uint32_t y) { return (int)(y & 0xFFFFu); }
+__device__ __forceinline__ uint32_t node_flags(uint32_t y) { return (y >> 16) & 0xFFu; }
+__device__ __forceinline__ int node_player(uint32_t y) { return (int)(int8_t)(y >> 24); }
+
+// getGameEnded(board, player) as float32 + the mask of `player` (yin_yang_game.py:80-110)
+template <int NW>
+__device__ __forceinline__ void leaf_rules(const YYGeo &geo, const GeoBB<NW> &gb, BB<NW> black, BB<NW> white,
+                                           int player, BB<NW> &mask, bool &terminal, float &tv) {
+    bool pre = bb_pre2x2(black, white, gb);
+    BB<NW> mb = bb_legal(black, white, pre, geo, gb), mw = bb_legal(white, black, pre, geo, gb);
+    int res = bb_result_black(black, white, mb, mw);
+    mask = (player == 1) ? mb : mw;
+    terminal = (res != 0);
+    tv = (res == 2) ? 0.0001f : ((player == 1) ? (float)res : (float)-res);
+}
+
+// ---- root prologue: mcts.py:288-295
+template <int NW> __global__ void __launch_bounds__(64) k_begin(MctsDev d, const int8_t *boards,
+                                                                const int8_t *players, const uint8_t *active,
+                                                                float *planes) {
+    const int g = blockIdx.x;
+    GameState *st = d.state + g;
+    const bool act = active ? (active[g] != 0) : true;
+    BB<NW> black, white;
+    board_to_bb<NW>(boards + (size_t)g * d.geo.A, d.geo.A, black, white);
+    if (lane_id() == 0) {
+        st->n_nodes = 1;  // node 0 = root
+        st->n_edges = 0;
+        st->root_N = 0;
+        st->root_W = 0.0f;
+        st->root_W_py = 0.0;
+        st->root_w_is_py = 1;
+        st->path_len = 0;
+        st->leaf_node = 0;
+        st->root_player = players[g];
+        st->active = act;
+        st->err = 0;
+        st->leaf_kind = act ? K_ROOTINIT : K_NONE;
+        d.nodes[(size_t)g * d.node_cap] = make_uint4(0u, node_pack(0, 0, players[g]), 0u, 0u);
+    }
+    uint64_t *gbd = d.gboard + (size_t)g * 2 * NW;
+    bb_store_lane0<NW>(gbd, black);
+    bb_store_lane0<NW>(gbd + NW, white);
+    if (!d.aliased) {
+        uint64_t *nb = d.nboard + (size_t)g * d.node_cap * 2 * NW;
+        bb_store_lane0<NW>(nb, black);
+        bb_store_lane0<NW>(nb + NW, white);
+    }
+    if (act) write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+}
+
+// ---- selection: mcts.py:356-362 (descent), 385-391 (state of the leaf), 63-71 (its rules)
+template <int NW>
+__device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *planes, uint8_t *needs_eval) {
+    GameState *st = d.state + g;
+    const int lane = lane_id();
+    if (!rfl((int)st->active) || rfl((int)st->err)) {
+        if (lane == 0) {
+            st->leaf_kind = K_NONE;
+            if (needs_eval) needs_eval[g] = 0;
+        }
+        return;
+    }
+    const GeoBB<NW> gb = geo_bb<NW>(d.geo);
+    const uint4 *nodes = d.nodes + (size_t)g * d.node_cap;
+    uint4 *edges = d.edges + (size_t)g * d.edge_cap;
+    int32_t *path = d.path + (size_t)g * d.path_cap;
+
+    int node = 0, depth = 0, parent = -1, action = -1, kind;
+    uint64_t c_levels = 0, c_scan = 0;
+    for (;;) {
+        const uint4 hdr = nodes[node];
+        const uint32_t hy = rfl(hdr.y);
+        const int k = node_k(hy), first = rfl((int)hdr.x);
+        if (node_flags(hy) & NF_TERMINAL) { kind = K_TERMINAL; break; }            // mcts.py:360, 365
+        if (k == 0) { kind = (node == 0) ? K_ROOTPASS : K_REEXPAND; break; }      // mcts.py:93-95
+        if (depth >= (int)d.path_cap) { kind = K_NONE; if (lane == 0) st->err = 1; break; }
+        // ---- Node.select_child (mcts.py:97-145), float32 order of SURVEY 8a/a12
+        int S = 0;
+        float bu = -INFINITY;
+        int bi = 0x7FFFFFFF;
+        uint32_t bw = 0;
+        // pass 1: sum of child visits (mcts.py:112)
+        for (int j = lane; j < k; j += 64) S += (int)edges[first + j].y;
+        S = wave_sum(S);
+        const float sq = d.sqrt_tab[min(S, d.sqrt_n - 1)];   // f32(math.sqrt(sum_visits))
+        for (int j = lane; j < k; j += 64) {
+            const uint4 e = edges[first + j];
+            const float P = __uint_as_float(e.x), W = __uint_as_float(e.z);
+            const int N = (int)e.y;
+            const float t1 = __fmul_rn(d.cpuct, P);
+            const float t2 = __fmul_rn(t1, sq);
+            const float u = __fdiv_rn(t2, (float)(1 + N));
+            const float q = (N > 0) ? __fdiv_rn(W, (float)N) : 0.0f;
+            const float ucb = __fadd_rn(q, u);
+            if (ucb > bu) { bu = ucb; bi = j; bw = e.w; }                          // strict >, mcts.py:133
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ou = __shfl_xor(bu, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const uint32_t ow = __shfl_xor(bw, o, 64);
+            if (ou > bu || (ou == bu && oi < bi)) { bu = ou; bi = oi; bw = ow; }   // lowest index wins ties
+        }
+        const int best = rfl(bi);
+        const uint32_t w = rfl(bw);
+        if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = 1; break; }  // NaN priors
+        if (lane == 0) path[depth] = first + best;
+        depth++;
+        c_levels++;
+        c_scan += (uint64_t)k;
+        parent = node;
+        action = (int)(w >> 24);
+        const uint32_t child = w & CHILD_NONE;
+        if (child == CHILD_NONE) { kind = K_EXPAND; node = -1; break; }
+        node = (int)child;
+    }
+
+    bool need = false;
+    if (kind == K_EXPAND || kind == K_REEXPAND || kind == K_ROOTPASS) {
+        BB<NW> black, white;
+        int lplayer;
+        if (kind == K_ROOTPASS) {                                                   // mcts.py:371-381
+            const uint64_t *src = d.aliased ? d.gboard + (size_t)g * 2 * NW : d.nboard + (size_t)g * d.node_cap * 2 * NW;
+            black = bb_uniform_load<NW>(src);
+            white = bb_uniform_load<NW>(src + NW);
+            lplayer = rfl((int)st->root_player);
+        } else {                                                                    // mcts.py:385-391
+            const uint64_t *src = d.aliased ? d.gboard + (size_t)g * 2 * NW
+                                            : d.nboard + ((size_t)g * d.node_cap + parent) * 2 * NW;
+            black = bb_uniform_load<NW>(src);
+            white = bb_uniform_load<NW>(src + NW);
+            const int pplayer = node_player(rfl(nodes[parent].y));
+            // getNextState: place iff legal (yin_yang_game.py:52-58).  In copied mode the action is
+            // one of the parent's legal moves on this very board, so it always places; in aliased
+            // mode the shared board has moved on and the full legality test is required.
+            bool ok = true;
+            if (d.aliased) {
+                bool pre = bb_pre2x2(black, white, gb);
+                BB<NW> m = (pplayer == 1) ? bb_legal(black, white, pre, d.geo, gb) : bb_legal(white, black, pre, d.geo, gb);
+                ok = bb_test(m, action);
+            }
+            if (ok) {
+                if (pplayer == 1) black = black | bb_bit<NW>(action);
+                else white = white | bb_bit<NW>(action);
+                if (d.aliased) {
+                    uint64_t *dst = d.gboard + (size_t)g * 2 * NW;
+                    bb_store_lane0<NW>(dst, black);
+                    bb_store_lane0<NW>(dst + NW, white);
+                }
+            }
+            lplayer = -pplayer;
+        }
+        BB<NW> mask;
+        bool term;
+        float tv;
+        leaf_rules<NW>(d.geo, gb, black, white, lplayer, mask, term, tv);
+        write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                st->leaf_board[i] = black.w[i];
+                st->leaf_board[NW + i] = white.w[i];
+                st->leaf_mask[i] = mask.w[i];
+            }
+            st->leaf_player = (int8_t)lplayer;
+            st->leaf_terminal = term;
+            st->leaf_tv = tv;
+        }
+        need = true;
+    }
+    if (lane == 0) {
+        st->leaf_kind = (uint8_t)kind;
+        st->leaf_node = node;
+        st->path_len = depth;
+        st->ctr[1] += c_levels;
+        st->ctr[2] += c_scan;
+        if (need) st->ctr[0] += 1;
+        if (kind == K_TERMINAL) st->ctr[4] += 1;
+        if (needs_eval) needs_eval[g] = need;
+    }
+}
+
+// ---- expansion + backup: mcts.py:50-91 (expand), 147-156 + 406-412 (update along the path)
+template <int NW>
+__device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, const float *policy,
+                                                 const float *value, const double *noise) {
+    GameState *st = d.state + g;
+    const int lane = lane_id();
+    const int kind = rfl((int)st->leaf_kind);
+    if (kind == K_NONE) return;
+    uint4 *nodes = d.nodes + (size_t)g * d.node_cap;
+    uint4 *edges = d.edges + (size_t)g * d.edge_cap;
+    const int32_t *path = d.path + (size_t)g * d.path_cap;
+    const int depth = rfl(st->path_len);
+    int node = rfl(st->leaf_node);
+    float v;
+    bool v_is_py = false;   // value is a python number (terminal value), not np.float32
+    if (kind == K_TERMINAL) {
+        v = rflf(__uint_as_float(nodes[node].z));                                   // mcts.py:366
+        v_is_py = true;
+    } else {
+        v = (kind == K_ROOTINIT) ? 0.0f : rflf(value[g]);
+        const int A = d.geo.A;
+        const int lplayer = rfl((int)st->leaf_player);
+        const bool term = rfl((int)st->leaf_terminal) != 0;
+        int n_nodes = rfl(st->n_nodes), n_edges = rfl(st->n_edges);
+        if (kind == K_EXPAND) {
+            if (n_nodes >= (int)d.node_cap) { if (lane == 0) { st->err = 1; st->leaf_kind = K_NONE; } return; }
+            node = n_nodes++;
+            if (lane == 0) {
+                uint4 *pe = edges + path[depth - 1];
+                pe->w = (pe->w & 0xFF000000u) | (uint32_t)node;
+                st->ctr[5] += 1;
+            }
+        }
+        BB<NW> mask;
+#pragma unroll
+        for (int i = 0; i < NW; i++) mask.w[i] = rfl64(st->leaf_mask[i]);
+        if (!d.aliased) {
+            uint64_t *nb = d.nboard + ((size_t)g * d.node_cap + node) * 2 * NW;
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * NW; i++) nb[i] = st->leaf_board[i];
+            }
+        }
+        if (term) {                                                                 // mcts.py:63-68
+            if (lane == 0)
+                nodes[node] = make_uint4(0u, node_pack(0, NF_TERMINAL, lplayer), __float_as_uint(st->leaf_tv), 0u);
+        } else {                                                                    // mcts.py:71-89
+            const int k = bb_popc(mask);
+            if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = 1; st->leaf_kind = K_NONE; } return; }
+            const float keep = (float)(1.0 - d.eps);
+            int base = n_edges;
+#pragma unroll
+            for (int j = 0; j < NW; j++) {
+                const int cell = j * 64 + lane;
+                if ((mask.w[j] >> lane) & 1) {
+                    float p = policy[(size_t)g * A + cell];
+                    if (noise) {                                                    // mcts.py:310-312
+                        const float kp = __fmul_rn(keep, p);
+                        p = (float)__dadd_rn((double)kp, __dmul_rn(d.eps, noise[(size_t)g * A + cell]));
+                    }
+                    edges[base + mbcnt(mask.w[j])] =
+                        make_uint4(__float_as_uint(p), 0u, 0u, CHILD_NONE | ((uint32_t)cell << 24));
+                }
+                base += yy_popc64(mask.w[j]);
+            }
+            if (lane == 0) {
+                nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, 0, lplayer), 0u, 0u);
+                st->ctr[3] += (uint64_t)k;
+            }
+            n_edges += k;
+        }
+        if (lane == 0) {
+            st->n_nodes = n_nodes;
+            st->n_edges = n_edges;
+        }
+    }
+    if (lane == 0) st->leaf_kind = K_NONE;
+    if (kind == K_ROOTINIT) return;                                                 // no backup
+    // ---- backup (mcts.py:406-412): edge i leads to the node at depth i+1; the leaf is at `depth`;
+    // players alternate every ply so the sign is the parity of the distance to the leaf.
+    for (int i = lane; i < depth; i += 64) {
+        uint4 *e = edges + path[i];
+        const int dist = depth - (i + 1);
+        const float sv = (dist & 1) ? -v : v;
+        uint4 r = *e;
+        r.y = (uint32_t)((int)r.y + 1);
+        r.z = __float_as_uint(__fadd_rn(__uint_as_float(r.z), sv));
+        *e = r;
+    }
+    if (lane == 0) {
+        const float sv = (depth & 1) ? -v : v;
+        st->root_N += 1;
+        if (st->root_w_is_py && v_is_py && depth == 0) {
+            // terminal root: python float + python number stays a python float (f64)
+            st->root_W_py += (double)((sv == 0.0001f) ? 0.0001 : (sv == -0.0001f ? -0.0001 : (double)sv));
+        } else {
+            const float base = st->root_w_is_py ? (float)st->root_W_py : st->root_W;
+            st->root_W = __fadd_rn(base, sv);
+            st->root_w_is_py = 0;
+        }
+    }
+}
+
+template <int NW> __global__ void __launch_bounds__(64) k_mcts(MctsDev d, int do_backup, int do_sel,
+                                                               const float *policy, const float *value,
+                                                               const double *noise, float *planes,
+                                                               uint8_t *needs_eval) {
+    const int g = blockIdx.x;
+    if (do_backup) do_expand_backup<NW>(d, g, policy, value, noise);
+    if (do_backup && do_sel) __syncthreads();   // edges/nodes written above are re-read below by other lanes
+    if (do_sel) do_select<NW>(d, g, planes, needs_eval);
+}
+
+template <int NW> __global__ void __launch_bounds__(64) k_root_counts(MctsDev d, int32_t *counts, float *cw, float *cp) {
+    const int g = blockIdx.x, A = d.geo.A;
+    const uint4 hdr = d.nodes[(size_t)g * d.node_cap];
+    const int k = node_k(rfl(hdr.y)), first = rfl((int)hdr.x);
+    const bool act = rfl((int)d.state[g].active) != 0;
+    for (int a = lane_id(); a < A; a += 64) {
+        counts[(size_t)g * A + a] = 0;
+        if (cw) cw[(size_t)g * A + a] = 0.0f;
+        if (cp) cp[(size_t)g * A + a] = 0.0f;
+    }
+    __syncthreads();
+    if (!act) return;
+    const uint4 *edges = d.edges + (size_t)g * d.edge_cap;
+    for (int j = lane_id(); j < k; j += 64) {
+        const uint4 e = edges[first + j];
+        const int a = (int)(e.w >> 24);
+        counts[(size_t)g * A + a] = (int)e.y;
+        if (cw) cw[(size_t)g * A + a] = __uint_as_float(e.z);
+        if (cp) cp[(size_t)g * A + a] = __uint_as_float(e.x);
+    }
+}
+
+// Node.get_children_distribution (mcts.py:183-215) for T == 1 and T == 0
+template <int NW> __global__ void __launch_bounds__(64) k_root_policy(MctsDev d, int tzero, double *pi) {
+    const int g = blockIdx.x, A = d.geo.A;
+    const uint4 hdr = d.nodes[(size_t)g * d.node_cap];
+    const int k = node_k(rfl(hdr.y)), first = rfl((int)hdr.x);
+    const uint4 *edges = d.edges + (size_t)g * d.edge_cap;
+    const bool act = rfl((int)d.state[g].active) != 0;
+    int sum = 0, mx = 0;
+    if (act)
+        for (int j = lane_id(); j < k; j += 64) {
+            int n = (int)edges[first + j].y;
+            sum += n;
+            mx = max(mx, n);
+        }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    double fill;
+    int nbest = 0;
+    if (tzero) {
+        // counts == max over ALL A actions (zeros included when max == 0), mcts.py:200-203
+        if (mx == 0) nbest = A;
+        else {
+            for (int j = lane_id(); j < k; j += 64) nbest += ((int)edges[first + j].y == mx);
+            nbest = wave_sum(nbest);
+        }
+        fill = (mx == 0) ? 1.0 / (double)A : 0.0;
+    } else {
+        fill = (sum > 0) ? 0.0 : 1.0 / (double)A;                                  // mcts.py:209-213
+    }
+    for (int a = lane_id(); a < A; a += 64) pi[(size_t)g * A + a] = act ? fill : 0.0;
+    __syncthreads();
+    if (!act) return;
+    if (tzero ? (mx > 0) : (sum > 0))
+        for (int j = lane_id(); j < k; j += 64) {
+            const uint4 e = edges[first + j];
+            const int a = (int)(e.w >> 24), n = (int)e.y;
+            pi[(size_t)g * A + a] = tzero ? ((n == mx) ? 1.0 / (double)nbest : 0.0) : (double)n / (double)sum;
+        }
+}
+
+__global__ void k_root_stats(MctsDev d, int32_t *visits, double *wsum) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    const GameState *st = d.state + g;
+    if (visits) visits[g] = st->root_N;
+    if (wsum) wsum[g] = st->root_w_is_py ? st->root_W_py : (double)st->root_W;
+}
+
+template <int NW> __global__ void __launch_bounds__(64) k_get_boards(MctsDev d, int8_t *boards) {
+    const int g = blockIdx.x;
+    const uint64_t *src = d.gboard + (size_t)g * 2 * NW;
+    BB<NW> b = bb_uniform_load<NW>(src), w = bb_uniform_load<NW>(src + NW);
+    bb_to_board<NW>(boards + (size_t)g * d.geo.A, d.geo.A, b, w);
+}
+
+__global__ void k_status(MctsDev d, uint64_t *out /*[8]: 6 counters, overflow games, 0*/) {
+    uint64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < d.G; g += gridDim.x * blockDim.x) {
+        const GameState *st = d.state + g;
+        for (int i = 0; i < 6; i++) acc[i] += st->ctr[i];
+        acc[6] += st->err ? 1 : 0;
+    }
+    for (int i = 0; i < 7; i++)
+        if (acc[i]) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
+}
+
+__global__ void k_reset_counters(MctsDev d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= d.G) return;
+    for (int i = 0; i < 6; i++) d.state[g].ctr[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------- host API
+extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
+    if (!cfg || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (int e = check_geo(cfg->G, cfg->R, cfg->C)) return e;
+    if (cfg->max_sims < 1) return set_err(YY_E_INVALID, "max_sims < 1%s%s");
+    yy_mcts *c = new yy_mcts();
+    memset(c, 0, sizeof *c);
+    c->cfg = *cfg;
+    yy_make_geo(&c->geo, cfg->R, cfg->C, cfg->flags & YY_FLAG_ROWCOL);
+    const int A = c->geo.A, NW = c->geo.NW;
+    c->node_cap = cfg->nodes_per_game > 0 ? cfg->nodes_per_game : (int64_t)cfg->max_sims + 2;
+    c->edge_cap = cfg->edges_per_game > 0 ? cfg->edges_per_game : ((int64_t)cfg->max_sims + 2) * A;
+    if (c->node_cap >= (int64_t)CHILD_NONE || c->edge_cap > 0x7FFFFFFFll)
+        { delete c; return set_err(YY_E_UNSUPPORTED, "arena per game too large%s%s"); }
+    // copied mode: every level places a stone, so depth <= A+1; aliased mode: depth <= sims
+    c->path_cap = (cfg->flags & YY_FLAG_ALIASED) ? (int64_t)cfg->max_sims + 2 : (int64_t)A + 2;
+    const size_t G = (size_t)cfg->G;
+    const bool copied = !(cfg->flags & YY_FLAG_ALIASED);
+    struct { void **p; size_t n; } allocs[] = {
+        {(void **)&c->edges, G * c->edge_cap * sizeof(uint4)},
+        {(void **)&c->nodes, G * c->node_cap * sizeof(uint4)},
+        {(void **)&c->nboard, copied ? G * c->node_cap * 2 * NW * sizeof(uint64_t) : 8},
+        {(void **)&c->gboard, G * 2 * NW * sizeof(uint64_t)},
+        {(void **)&c->path, G * c->path_cap * sizeof(int32_t)},
+        {(void **)&c->state, G * sizeof(GameState)},
+        {(void **)&c->sqrt_tab, (size_t)(cfg->max_sims + 2) * sizeof(float)},
+        {(void **)&c->scratch, 8 * sizeof(uint64_t)},
+    };
+    for (auto &a : allocs) {
+        if (hipMalloc(a.p, a.n) != hipSuccess) {
+            (void)hipGetLastError();
+            yy_mcts_destroy(c);
+            return set_err(YY_E_NOMEM, "hipMalloc failed%s%s");
+        }
+        c->bytes += a.n;
+    }
+    HIP_TRY(hipMemset(c->state, 0, G * sizeof(GameState)));
+    HIP_TRY(hipMemset(c->nodes, 0, G * c->node_cap * sizeof(uint4)));
+    // f32(math.sqrt(S)) table built with the host's correctly rounded double sqrt (mcts.py:130)
+    float *tab = new float[cfg->max_sims + 2];
+    for (int s = 0; s < cfg->max_sims + 2; s++) tab[s] = (float)sqrt((double)s);
+    hipError_t e = hipMemcpy(c->sqrt_tab, tab, (size_t)(cfg->max_sims + 2) * sizeof(float), hipMemcpyHostToDevice);
+    delete[] tab;
+    if (e != hipSuccess) { yy_mcts_destroy(c); return set_err(YY_E_HIP, "hipMemcpy: %s%s", hipGetErrorString(e)); }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = c;
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_destroy(yy_mcts *c) {
+    if (!c) return YY_OK;
+    void *ps[] = {c->edges, c->nodes, c->nboard, c->gboard, c->path, c->state, c->sqrt_tab, c->scratch};
+    for (void *p : ps)
+        if (p) (void)hipFree(p);
+    delete c;
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_memory_bytes(const yy_mcts *c, uint64_t *out) {
+    if (!c || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
+    *out = c->bytes;
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_begin(yy_mcts *c, const int8_t *boards, const int8_t *players, const uint8_t *active,
+                             float *planes, yy_stream_t s) {
+    if (!c || !boards || !players || !planes) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    DISPATCH_NW(c->geo.NW, k_begin<NW><<<dim3(c->cfg.G), dim3(64), 0, (hipStream_t)s>>>(d, boards,
+                                               players, active, planes));
+    HIP_TRY(hipGetLastError());
+    c->pending = 2;  // root expansion pending
+    return YY_OK;
+}
+
+static int launch_mcts(yy_mcts *c, int backup, int sel, const float *policy, const float *value, const double *noise,
+                       double eps, float *planes, uint8_t *needs_eval, yy_stream_t s) {
+    MctsDev d = make_dev(c);
+    d.eps = eps;
+    DISPATCH_NW(c->geo.NW, k_mcts<NW><<<dim3(c->cfg.G), dim3(64), 0, (hipStream_t)s>>>(d, backup, sel,
+                                               policy, value, noise, planes, needs_eval));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_expand_root(yy_mcts *c, const float *policy, const double *noise, double eps, yy_stream_t s) {
+    if (!c || !policy) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (c->pending != 2) return set_err(YY_E_STATE, "yy_mcts_expand_root without yy_mcts_begin%s%s");
+    int e = launch_mcts(c, 1, 0, policy, nullptr, noise, eps, nullptr, nullptr, s);
+    if (e == YY_OK) c->pending = 0;
+    return e;
+}
+
+extern "C" int yy_mcts_select(yy_mcts *c, float *planes, uint8_t *needs_eval, yy_stream_t s) {
+    if (!c || !planes) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (c->pending != 0) return set_err(YY_E_STATE, "yy_mcts_select with an expansion pending%s%s");
+    int e = launch_mcts(c, 0, 1, nullptr, nullptr, nullptr, 0.0, planes, needs_eval, s);
+    if (e == YY_OK) c->pending = 1;
+    return e;
+}
+
+extern "C" int yy_mcts_expand_backup(yy_mcts *c, const float *policy, const float *value, yy_stream_t s) {
+    if (!c || !policy || !value) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (c->pending != 1) return set_err(YY_E_STATE, "yy_mcts_expand_backup without yy_mcts_select%s%s");
+    int e = launch_mcts(c, 1, 0, policy, value, nullptr, 0.0, nullptr, nullptr, s);
+    if (e == YY_OK) c->pending = 0;
+    return e;
+}
+
+extern "C" int yy_mcts_step(yy_mcts *c, const float *policy, const float *value, float *planes, uint8_t *needs_eval,
+                            yy_stream_t s) {
+    if (!c || !policy || !value || !planes) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (c->pending != 1) return set_err(YY_E_STATE, "yy_mcts_step without a pending select%s%s");
+    return launch_mcts(c, 1, 1, policy, value, nullptr, 0.0, planes, needs_eval, s);
+}
+
+extern "C" int yy_mcts_root_counts(yy_mcts *c, int32_t *counts, float *cw, float *cp, yy_stream_t s) {
+    if (!c || !counts) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    DISPATCH_NW(c->geo.NW,
+                k_root_counts<NW><<<dim3(c->cfg.G), dim3(64), 0, (hipStream_t)s>>>(d, counts, cw, cp));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_root_policy(yy_mcts *c, int tzero, double *pi, yy_stream_t s) {
+    if (!c || !pi) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    DISPATCH_NW(c->geo.NW,
+                k_root_policy<NW><<<dim3(c->cfg.G), dim3(64), 0, (hipStream_t)s>>>(d, tzero, pi));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_root_stats(yy_mcts *c, int32_t *visits, double *wsum, yy_stream_t s) {
+    if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    hipLaunchKernelGGL(k_root_stats, dim3((c->cfg.G + 255) / 256), dim3(256), 0, (hipStream_t)s, d, visits, wsum);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_get_boards(yy_mcts *c, int8_t *boards, yy_stream_t s) {
+    if (!c || !boards) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    DISPATCH_NW(c->geo.NW, k_get_boards<NW><<<dim3(c->cfg.G), dim3(64), 0, (hipStream_t)s>>>(d, boards));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counters) {
+    if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(c->scratch, 0, 8 * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_status, dim3(64), dim3(256), 0, 0, d, c->scratch);
+    HIP_TRY(hipGetLastError());
+    uint64_t h[8];
+    HIP_TRY(hipMemcpy(h, c->scratch, sizeof h, hipMemcpyDeviceToHost));
+    if (counters) {
+        for (int i = 0; i < 6; i++) counters[i] = h[i];
+        counters[6] = counters[7] = 0;
+    }
+    if (n_overflow) *n_overflow = (int32_t)h[6];
+    if (h[6]) return set_err(YY_E_ARENA, "tree arena overflow in at least one game%s%s");
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_reset_counters(yy_mcts *c, yy_stream_t s) {
+    if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
+    MctsDev d = make_dev(c);
+    hipLaunchKernelGGL(k_reset_counters, dim3((c->cfg.G + 255) / 256), dim3(256), 0, (hipStream_t)s, d);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}

@@ -1,0 +1,259 @@
+"""Torch-tensor level binding of the HIP hot path (include/yy_engine.h).
+
+PyTorch is plumbing here: it owns the HBM tensors and the stream; every operation below is a
+hand-written gfx950 kernel in csrc/yy_engine.hip.  No CPU fallback exists: tensors must be on a
+ROCm device and the extension must be built, otherwise these functions raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import FLAG_ALIASED, FLAG_ROWCOL, MctsConfig, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t, dtype, shape=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.YYError(-1, f"{name}: expected a ROCm device tensor (the hot path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.YYError(-1, f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.YYError(-1, f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _flags(rowcol=False, aliased=False):
+    return (FLAG_ROWCOL if rowcol else 0) | (FLAG_ALIASED if aliased else 0)
+
+
+# ------------------------------------------------------------------ stateless rules kernels
+def valid_mask(boards, players, rowcol=False):
+    """getValidMoves for a batch (yin_yang_game.py:60-78): int8 [G,R,C], int8 [G] -> uint8 [G,A]."""
+    G, R, Cc = boards.shape
+    _need(boards, torch.int8, name="boards")
+    _need(players, torch.int8, (G,), "players")
+    out = torch.empty((G, R * Cc), dtype=torch.uint8, device=boards.device)
+    with torch.cuda.device(boards.device):
+        check(lib().yy_rules_valid_mask(_p(boards), _p(players), G, R, Cc, _flags(rowcol), _p(out), _stream()))
+    return out
+
+
+def step_(boards, players, actions, rowcol=False):
+    """getNextState IN PLACE (yin_yang_game.py:39-58): boards and players are updated; returns the
+    uint8 [G] `placed` bits (illegal placements are silently skipped, the player still flips)."""
+    G, R, Cc = boards.shape
+    _need(boards, torch.int8, name="boards")
+    _need(players, torch.int8, (G,), "players")
+    _need(actions, torch.int32, (G,), "actions")
+    placed = torch.empty(G, dtype=torch.uint8, device=boards.device)
+    with torch.cuda.device(boards.device):
+        check(lib().yy_rules_step(_p(boards), _p(players), _p(actions), G, R, Cc, _flags(rowcol), _p(placed), _stream()))
+    return placed
+
+
+def game_ended(boards, players, rowcol=False, with_counts=False):
+    """getGameEnded (yin_yang_game.py:80-110): float64 [G] in {0, 1, -1, 0.0001}."""
+    G, R, Cc = boards.shape
+    _need(boards, torch.int8, name="boards")
+    _need(players, torch.int8, (G,), "players")
+    out = torch.empty(G, dtype=torch.float64, device=boards.device)
+    counts = torch.empty((G, 2), dtype=torch.int32, device=boards.device) if with_counts else None
+    with torch.cuda.device(boards.device):
+        check(lib().yy_rules_game_ended(_p(boards), _p(players), G, R, Cc, _flags(rowcol), _p(out), _p(counts), _stream()))
+    return (out, counts) if with_counts else out
+
+
+def encode_planes(boards, out=None):
+    """board_to_input for a batch (neural_network.py:156-196): float32 [G,5,R,C]."""
+    G, R, Cc = boards.shape
+    _need(boards, torch.int8, name="boards")
+    if out is None:
+        out = torch.empty((G, 5, R, Cc), dtype=torch.float32, device=boards.device)
+    _need(out, torch.float32, (G, 5, R, Cc), "out")
+    with torch.cuda.device(boards.device):
+        check(lib().yy_encode_planes(_p(boards), G, R, Cc, _p(out), _stream()))
+    return out
+
+
+def pack_boards(boards):
+    """int8 [G,R,C] -> (black, white) uint64-as-int64 [NW,G] word-major bitboards."""
+    G, R, Cc = boards.shape
+    _need(boards, torch.int8, name="boards")
+    nw = (R * Cc + 63) // 64
+    black = torch.empty((nw, G), dtype=torch.int64, device=boards.device)
+    white = torch.empty((nw, G), dtype=torch.int64, device=boards.device)
+    with torch.cuda.device(boards.device):
+        check(lib().yy_pack_boards(_p(boards), G, R, Cc, _p(black), _p(white), _stream()))
+    return black, white
+
+
+def unpack_boards(black, white, R, Cc):
+    nw, G = black.shape
+    _need(black, torch.int64, name="black")
+    _need(white, torch.int64, (nw, G), "white")
+    boards = torch.empty((G, R, Cc), dtype=torch.int8, device=black.device)
+    with torch.cuda.device(black.device):
+        check(lib().yy_unpack_boards(_p(black), _p(white), G, R, Cc, _p(boards), _stream()))
+    return boards
+
+
+def mask_terminal_bb(black, white, R, Cc, rowcol=False, out=None):
+    """Packed rules kernel: both colours' legal masks + game-ended code from BLACK's view
+    (0 ongoing, 1, -1, 2 draw) for bitboards [NW,G]."""
+    nw, G = black.shape
+    _need(black, torch.int64, name="black")
+    _need(white, torch.int64, (nw, G), "white")
+    if out is None:
+        out = (torch.empty_like(black), torch.empty_like(black),
+               torch.empty(G, dtype=torch.int8, device=black.device))
+    m1, m2, res = out
+    with torch.cuda.device(black.device):
+        check(lib().yy_rules_mask_terminal_bb(_p(black), _p(white), G, R, Cc, _flags(rowcol), _p(m1), _p(m2), _p(res), _stream()))
+    return m1, m2, res
+
+
+# ------------------------------------------------------------------ batched MCTS context
+class BatchedMCTS:
+    """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate
+    (ai/mcts.py:28-225, 275-414).  One game per wavefront; see csrc/yy_engine.hip."""
+
+    COUNTERS = ("evals", "levels", "children_scanned", "children_created", "terminal_revisits", "nodes")
+
+    def __init__(self, G, R, C, max_sims, cpuct=1.0, aliased=False, rowcol=False, device=None,
+                 edges_per_game=0, nodes_per_game=0):
+        if not torch.cuda.is_available():
+            raise _lib.YYError(-100, "BatchedMCTS needs a ROCm device: the hot path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.G, self.R, self.C, self.A = int(G), int(R), int(C), int(R) * int(C)
+        self.max_sims, self.cpuct, self.aliased, self.rowcol = int(max_sims), float(cpuct), bool(aliased), bool(rowcol)
+        cfg = MctsConfig(self.G, self.R, self.C, self.max_sims, self.cpuct, _flags(rowcol, aliased),
+                         int(edges_per_game), int(nodes_per_game))
+        h = C_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.planes = torch.zeros((self.G, 5, self.R, self.C), dtype=torch.float32, device=self.device)
+        self.needs_eval = torch.zeros(self.G, dtype=torch.uint8, device=self.device)
+        self._keep = []   # tensors referenced by enqueued kernels
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            lib().yy_mcts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def memory_bytes(self):
+        n = C.c_uint64(0)
+        check(lib().yy_mcts_memory_bytes(self._h, C.byref(n)))
+        return n.value
+
+    # -- the C ABI, one method per entry point
+    def begin(self, boards, root_players, active=None):
+        _need(boards, torch.int8, (self.G, self.R, self.C), "boards")
+        _need(root_players, torch.int8, (self.G,), "root_players")
+        if active is not None:
+            _need(active, torch.uint8, (self.G,), "active")
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_begin(self._h, _p(boards), _p(root_players), _p(active), _p(self.planes), _stream()))
+
+    def expand_root(self, policy, noise=None, eps=0.25):
+        _need(policy, torch.float32, (self.G, self.A), "policy")
+        if noise is not None:
+            _need(noise, torch.float64, (self.G, self.A), "noise")
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_expand_root(self._h, _p(policy), _p(noise), float(eps), _stream()))
+
+    def select(self):
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_select(self._h, _p(self.planes), _p(self.needs_eval), _stream()))
+
+    def expand_backup(self, policy, value):
+        _need(policy, torch.float32, (self.G, self.A), "policy")
+        _need(value, torch.float32, (self.G,), "value")
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_expand_backup(self._h, _p(policy), _p(value), _stream()))
+
+    def step(self, policy, value):
+        _need(policy, torch.float32, (self.G, self.A), "policy")
+        _need(value, torch.float32, (self.G,), "value")
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_step(self._h, _p(policy), _p(value), _p(self.planes), _p(self.needs_eval), _stream()))
+
+    def root_counts(self, with_children=False):
+        counts = torch.empty((self.G, self.A), dtype=torch.int32, device=self.device)
+        cw = torch.empty((self.G, self.A), dtype=torch.float32, device=self.device) if with_children else None
+        cp = torch.empty((self.G, self.A), dtype=torch.float32, device=self.device) if with_children else None
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_root_counts(self._h, _p(counts), _p(cw), _p(cp), _stream()))
+        return (counts, cw, cp) if with_children else counts
+
+    def root_policy(self, temperature_zero=False):
+        pi = torch.empty((self.G, self.A), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_root_policy(self._h, int(bool(temperature_zero)), _p(pi), _stream()))
+        return pi
+
+    def root_stats(self):
+        visits = torch.empty(self.G, dtype=torch.int32, device=self.device)
+        wsum = torch.empty(self.G, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_root_stats(self._h, _p(visits), _p(wsum), _stream()))
+        return visits, wsum
+
+    def boards(self):
+        out = torch.empty((self.G, self.R, self.C), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_get_boards(self._h, _p(out), _stream()))
+        return out
+
+    def status(self):
+        """sync; raises YYError(YY_E_ARENA) when a game's arena overflowed; returns the counters."""
+        n = C.c_int32(0)
+        ctr = (C.c_uint64 * 8)()
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_status(self._h, C.byref(n), ctr))
+        return dict(zip(self.COUNTERS, [int(x) for x in ctr[:6]]))
+
+    def reset_counters(self):
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_reset_counters(self._h, _stream()))
+
+    # -- the whole of MCTS.search for G games (mcts.py:275-343)
+    def search(self, boards, root_players, evaluator, num_sims, noise=None, eps=0.25, active=None, fused=True):
+        """evaluator(planes f32[G,5,R,C]) -> (policy f32[G,A] softmax, value f32[G]) on device.
+        Runs 1 + num_sims evaluator calls exactly like the reference (root call, then one per
+        simulation) and returns the root visit counts int32 [G,A]."""
+        if num_sims > self.max_sims:
+            raise _lib.YYError(-1, f"num_sims {num_sims} > max_sims {self.max_sims} the context was sized for")
+        self.begin(boards, root_players, active)
+        policy, _ = evaluator(self.planes)
+        self.expand_root(policy, noise, eps)
+        self.select()
+        for s in range(num_sims):
+            policy, value = evaluator(self.planes)
+            if fused and s + 1 < num_sims:
+                self.step(policy, value)
+            else:
+                self.expand_backup(policy, value)
+                if s + 1 < num_sims:
+                    self.select()
+        return self.root_counts()
+
+
+def C_void_p():
+    return C.c_void_p()
