@@ -1,0 +1,207 @@
+"""GPU parity, search path: BatchedMCTS (HIP kernels through the C ABI) against MCTS.search of the
+imported reference (G3 fixtures) with the exact dyadic hash evaluator computed on the host from the
+planes the kernel wrote.  Identical visit counts / float32 value sums / priors / evaluator call
+order / mutated boards; pi identical (tolerance 0, well inside the 1e-5 of the north star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from hash_eval import hash_eval_batch, planes_to_boards
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SEARCH = sorted(glob.glob(os.path.join(GOLDEN, "search_[0-9]*.npz")))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available()
+    import yinyang_game_alphazero_amd as pkg
+    return pkg
+
+
+class HostHashEvaluator:
+    """policy/value from the planes the select kernel wrote; logs the evaluated boards per game."""
+
+    def __init__(self, pbits, vbits, needs_eval=None):
+        self.pbits, self.vbits = np.asarray(pbits), np.asarray(vbits)
+        self.calls = 0
+        self.logs = [[] for _ in self.pbits]
+        self.needs_eval = needs_eval
+
+    def __call__(self, planes):
+        import torch
+        b = planes_to_boards(planes.cpu().numpy())
+        G, A = b.shape[0], b.shape[1] * b.shape[2]
+        pol = np.zeros((G, A), np.float32)
+        val = np.zeros(G, np.float32)
+        for pb, vb in set(zip(self.pbits.tolist(), self.vbits.tolist())):
+            idx = np.flatnonzero((self.pbits == pb) & (self.vbits == vb))
+            pol[idx], val[idx] = hash_eval_batch(b[idx], pb, vb)
+        if self.calls > 0 and self.needs_eval is not None:
+            ne = self.needs_eval.cpu().numpy()
+            for g in np.flatnonzero(ne):
+                self.logs[g].append(b[g].copy())
+        self.calls += 1
+        return torch.from_numpy(pol).cuda(), torch.from_numpy(val).cuda()
+
+
+def _run_group(pkg, z, idx, fused):
+    import torch
+    R, C = z["root_board"].shape[1:]
+    sims, copied = int(z["sims"][idx[0]]), int(z["copied"][idx[0]])
+    G = len(idx)
+    m = pkg.engine.BatchedMCTS(G, R, C, sims, cpuct=1.0, aliased=not copied)
+    ev = HostHashEvaluator(z["pbits"][idx], z["vbits"][idx], m.needs_eval)
+    boards = torch.from_numpy(z["root_board"][idx]).cuda()
+    players = torch.from_numpy(z["root_player"][idx]).cuda()
+    noise = torch.from_numpy(z["noise"][idx]).cuda()     # zeros where has_noise == 0 -> p = f32(.75p + 0) != p
+    has = z["has_noise"][idx].astype(bool)
+    # games without noise must keep the raw prior: run them in a separate context call
+    assert has.all() or (~has).all()
+    counts = m.search(boards, players, ev, sims, noise=noise if has.all() else None, fused=fused)
+    c2, cw, cp = m.root_counts(with_children=True)
+    visits, wsum = m.root_stats()
+    pi = m.root_policy()
+    fb = m.boards()
+    m.status()
+    torch.cuda.synchronize()
+    for j, i in enumerate(idx):
+        tag = f"case {i} sims {sims} copied {copied}"
+        assert np.array_equal(counts[j].cpu().numpy(), z["counts"][i]), tag
+        assert np.array_equal(c2[j].cpu().numpy(), z["counts"][i]), tag
+        assert np.array_equal(cp[j].cpu().numpy(), z["child_p"][i]), tag
+        assert np.array_equal(cw[j].cpu().numpy().astype(np.float64), z["child_w"][i]), tag
+        assert int(visits[j]) == int(z["root_visits"][i]), tag
+        assert float(wsum[j]) == float(z["root_w"][i]), tag
+        assert np.array_equal(pi[j].cpu().numpy(), z["pi"][i]), tag
+        assert np.array_equal(fb[j].cpu().numpy(), z["final_board"][i]), tag
+        assert len(ev.logs[j]) == int(z["n_evals"][i]), tag
+        nl = int(z["n_leaves"][i])
+        if nl:
+            assert np.array_equal(np.stack(ev.logs[j]), z["leaves"][i, :nl]), tag
+    m.close()
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_step", "select+expand"])
+@pytest.mark.parametrize("path", SEARCH, ids=[os.path.basename(p) for p in SEARCH])
+def test_search_golden(pkg, path, fused):
+    z = np.load(path)
+    n = z["counts"].shape[0]
+    groups = {}
+    for i in range(n):
+        groups.setdefault((int(z["sims"][i]), int(z["copied"][i]), int(z["has_noise"][i])), []).append(i)
+    for key, idx in sorted(groups.items()):
+        if not fused and key[0] > 200:
+            continue
+        _run_group(pkg, z, np.asarray(idx), fused)
+
+
+def test_search_recorded_network(pkg):
+    """Real 128x10 net recorded from the reference run: replay its outputs row by row."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "search_net_8x8.npz"))
+    for i in range(z["counts"].shape[0]):
+        n, sims, copied = int(z["n_rec"][i]), int(z["sims"][i]), int(z["copied"][i])
+        m = pkg.engine.BatchedMCTS(1, 8, 8, sims, aliased=not copied)
+        state = {"k": 0}
+        recp, recv = z["rec_policy"][i], z["rec_value"][i]
+        seen = []
+
+        def ev(planes):
+            k = state["k"]
+            if k > 0 and int(m.needs_eval[0]) == 0:
+                return torch.zeros((1, 64), device="cuda"), torch.zeros(1, device="cuda")
+            seen.append(planes_to_boards(planes.cpu().numpy())[0])
+            state["k"] = k + 1
+            return torch.from_numpy(recp[k:k + 1]).cuda(), torch.from_numpy(recv[k:k + 1]).cuda()
+
+        noise = torch.from_numpy(z["noise"][i:i + 1]).cuda() if z["has_noise"][i] else None
+        counts = m.search(torch.from_numpy(z["root_board"][i:i + 1]).cuda(), torch.ones(1, dtype=torch.int8, device="cuda"),
+                          ev, sims, noise=noise)
+        assert state["k"] == n
+        assert np.array_equal(np.stack(seen), z["rec_boards"][i, :n])
+        assert np.array_equal(counts[0].cpu().numpy(), z["counts"][i])
+        assert np.array_equal(m.root_policy()[0].cpu().numpy(), z["pi"][i])
+        assert np.array_equal(m.boards()[0].cpu().numpy(), z["final_board"][i])
+        m.close()
+
+
+@pytest.mark.parametrize("shape,sims,copied", [((8, 8), 800, 1), ((8, 8), 800, 0), ((12, 12), 400, 1), ((6, 6), 200, 1),
+                                               ((13, 13), 100, 1), ((16, 12), 60, 1), ((3, 3), 64, 1)])
+def test_search_vs_oracle_batch(pkg, shape, sims, copied):
+    """A batch of fresh seeded roots (random legal-play positions, both root players, coarse and fine
+    evaluators, with noise) against the CPU oracle."""
+    import torch
+    R, C = shape
+    A = R * C
+    G = 48
+    rng = np.random.default_rng(sims + R)
+    boards = np.zeros((G, R, C), np.int8)
+    pl = np.ones(G, np.int8)
+    for ply in range(A):
+        m = O.valid_mask(boards, pl)
+        go = (rng.random(G) < 0.93) & m.any(1)
+        act = np.array([rng.choice(np.flatnonzero(r)) if r.any() else 0 for r in m], np.int32)
+        nb, npl, _ = O.next_state(boards, pl, act)
+        boards[go], pl[go] = nb[go], npl[go]
+    players = rng.choice(np.array([1, -1], np.int8), size=G)
+    pb = rng.choice([10, 2, 6], size=G)
+    vb = np.where(pb == 10, 11, np.where(pb == 2, 2, 4))
+    noise = np.zeros((G, A))
+    valid = O.valid_mask(boards, players)
+    for g in range(G):
+        k = int(valid[g].sum())
+        if k:
+            noise[g, valid[g] == 1] = rng.dirichlet([0.3] * k)
+    m = pkg.engine.BatchedMCTS(G, R, C, sims, aliased=not copied)
+    ev = HostHashEvaluator(pb, vb, m.needs_eval)
+    counts = m.search(torch.from_numpy(boards).cuda(), torch.from_numpy(players).cuda(), ev, sims,
+                      noise=torch.from_numpy(noise).cuda())
+    c2, cw, cp = m.root_counts(with_children=True)
+    fb = m.boards().cpu().numpy()
+    visits, wsum = m.root_stats()
+    m.status()
+    for g in range(G):
+        r = O.search_hash(boards[g], int(players[g]), sims, copied, int(pb[g]), int(vb[g]), noise=noise[g])
+        assert np.array_equal(counts[g].cpu().numpy(), r.counts), g
+        assert np.array_equal(cw[g].cpu().numpy().astype(np.float64), r.child_w), g
+        assert np.array_equal(cp[g].cpu().numpy(), r.child_p), g
+        assert np.array_equal(fb[g], r.final_board), g
+        assert len(ev.logs[g]) == r.n_evals, g
+        assert int(visits[g]) == sims and float(wsum[g]) == r.root_w, g
+    m.close()
+
+
+def test_inactive_games_and_state_errors(pkg):
+    import torch
+    m = pkg.engine.BatchedMCTS(4, 6, 6, 16)
+    with pytest.raises(pkg.YYError):
+        m.select()   # nothing begun... select before expand_root is a state error only after begin
+        m.expand_backup(torch.zeros((4, 36), device="cuda"), torch.zeros(4, device="cuda"))
+        m.expand_backup(torch.zeros((4, 36), device="cuda"), torch.zeros(4, device="cuda"))
+    m.close()
+    m = pkg.engine.BatchedMCTS(4, 6, 6, 16)
+    active = torch.tensor([1, 0, 1, 0], dtype=torch.uint8, device="cuda")
+    ev = HostHashEvaluator([10] * 4, [11] * 4, m.needs_eval)
+    counts = m.search(torch.zeros((4, 6, 6), dtype=torch.int8, device="cuda"), torch.ones(4, dtype=torch.int8, device="cuda"),
+                      ev, 16, active=active)
+    c = counts.cpu().numpy()
+    assert c[0].sum() == 16 and c[2].sum() == 16 and c[1].sum() == 0 and c[3].sum() == 0
+    assert np.array_equal(c[0], c[2])
+    m.close()
+
+
+def test_arena_overflow_is_a_status(pkg):
+    import torch
+    m = pkg.engine.BatchedMCTS(2, 8, 8, 64, edges_per_game=100, nodes_per_game=8)
+    ev = HostHashEvaluator([10, 10], [11, 11], m.needs_eval)
+    m.search(torch.zeros((2, 8, 8), dtype=torch.int8, device="cuda"), torch.ones(2, dtype=torch.int8, device="cuda"), ev, 64)
+    with pytest.raises(pkg.YYError) as ei:
+        m.status()
+    assert ei.value.code == -6
+    m.close()

@@ -522,7 +522,27 @@ template <int NW> __global__ void __launch_bounds__(64) k_begin(MctsDev d, const
         bb_store_lane0<NW>(nb, black);
         bb_store_lane0<NW>(nb + NW, white);
     }
-    if (act) write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+    if (act) {
+        // root.expand's rules (mcts.py:63-71) for the pending K_ROOTINIT expansion
+        const GeoBB<NW> gb = geo_bb<NW>(d.geo);
+        const int rp = rfl((int)players[g]);
+        BB<NW> mask;
+        bool term;
+        float tv;
+        leaf_rules<NW>(d.geo, gb, black, white, rp, mask, term, tv);
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                st->leaf_board[i] = black.w[i];
+                st->leaf_board[NW + i] = white.w[i];
+                st->leaf_mask[i] = mask.w[i];
+            }
+            st->leaf_player = (int8_t)rp;
+            st->leaf_terminal = term;
+            st->leaf_tv = tv;
+        }
+        write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+    }
 }
 
 // ---- selection: mcts.py:356-362 (descent), 385-391 (state of the leaf), 63-71 (its rules)

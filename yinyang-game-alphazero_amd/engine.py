@@ -4,7 +4,7 @@ PyTorch is plumbing here: it owns the HBM tensors and the stream; every operatio
 hand-written gfx950 kernel in csrc/yy_engine.hip.  No CPU fallback exists: tensors must be on a
 ROCm device and the extension must be built, otherwise these functions raise.
 """
-import ctypes as C
+import ctypes as ct
 
 import torch
 
@@ -13,11 +13,11 @@ from ._lib import FLAG_ALIASED, FLAG_ROWCOL, MctsConfig, check, lib
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else ct.c_void_p(t.data_ptr())
 
 
 def _need(t, dtype, shape=None, name="tensor"):
@@ -138,7 +138,7 @@ class BatchedMCTS:
                          int(edges_per_game), int(nodes_per_game))
         h = C_void_p()
         with torch.cuda.device(self.device):
-            check(lib().yy_mcts_create(C.byref(cfg), C.byref(h)))
+            check(lib().yy_mcts_create(ct.byref(cfg), ct.byref(h)))
         self._h = h
         self.planes = torch.zeros((self.G, 5, self.R, self.C), dtype=torch.float32, device=self.device)
         self.needs_eval = torch.zeros(self.G, dtype=torch.uint8, device=self.device)
@@ -158,8 +158,8 @@ class BatchedMCTS:
             pass
 
     def memory_bytes(self):
-        n = C.c_uint64(0)
-        check(lib().yy_mcts_memory_bytes(self._h, C.byref(n)))
+        n = ct.c_uint64(0)
+        check(lib().yy_mcts_memory_bytes(self._h, ct.byref(n)))
         return n.value
 
     # -- the C ABI, one method per entry point
@@ -223,10 +223,10 @@ class BatchedMCTS:
 
     def status(self):
         """sync; raises YYError(YY_E_ARENA) when a game's arena overflowed; returns the counters."""
-        n = C.c_int32(0)
-        ctr = (C.c_uint64 * 8)()
+        n = ct.c_int32(0)
+        ctr = (ct.c_uint64 * 8)()
         with torch.cuda.device(self.device):
-            check(lib().yy_mcts_status(self._h, C.byref(n), ctr))
+            check(lib().yy_mcts_status(self._h, ct.byref(n), ctr))
         return dict(zip(self.COUNTERS, [int(x) for x in ctr[:6]]))
 
     def reset_counters(self):
@@ -256,4 +256,4 @@ class BatchedMCTS:
 
 
 def C_void_p():
-    return C.c_void_p()
+    return ct.c_void_p()

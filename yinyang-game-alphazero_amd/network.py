@@ -1,0 +1,174 @@
+"""Policy/value CNN of the reference under PyTorch-ROCm, plus the batched evaluator the lockstep
+engine feeds.
+
+`YinYangNeuralNetwork` mirrors src/yin_yang/ai/neural_network.py:35-237 (same constructor, same
+parameter names so reference checkpoints load unchanged, same predict/board_to_input/save/load
+surface).  The architecture is the reference's: 5 input planes -> 3x3 stem -> N residual blocks of
+two 3x3 convs -> policy head (1x1 to 32 ch, FC to A) and value head (1x1 to 32 ch, FC 256, FC 1,
+tanh).  What is new here is the batched path: `predict_batch` / `BatchedEvaluator` evaluate all G
+leaf positions of a lockstep step in ONE forward on the device (the reference evaluates one board
+per call on the CPU, self_play.py:54-59).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HEAD_CHANNELS = 32
+VALUE_HIDDEN = 256
+INPUT_PLANES = 5
+
+
+class ResidualBlock(nn.Module):
+    """conv-bn-relu-conv-bn + skip, relu (neural_network.py:16-33); attribute names fixed by the
+    checkpoint format."""
+
+    def __init__(self, channels):
+        super().__init__()
+        for i in (1, 2):
+            setattr(self, f"conv{i}", nn.Conv2d(channels, channels, 3, padding=1))
+            setattr(self, f"bn{i}", nn.BatchNorm2d(channels))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + x)
+
+
+class YinYangNeuralNetwork(nn.Module):
+    def __init__(self, game, num_channels=128, num_res_blocks=10):
+        super().__init__()
+        self.game = game
+        self.board_size = tuple(game.getBoardSize())
+        self.action_size = game.getActionSize()
+        self.input_channels = INPUT_PLANES
+        cells = self.board_size[0] * self.board_size[1]
+        self.conv1 = nn.Conv2d(INPUT_PLANES, num_channels, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(num_channels)
+        self.res_blocks = nn.ModuleList(ResidualBlock(num_channels) for _ in range(num_res_blocks))
+        self.policy_conv = nn.Conv2d(num_channels, HEAD_CHANNELS, 1)
+        self.policy_bn = nn.BatchNorm2d(HEAD_CHANNELS)
+        self.policy_fc = nn.Linear(HEAD_CHANNELS * cells, self.action_size)
+        self.value_conv = nn.Conv2d(num_channels, HEAD_CHANNELS, 1)
+        self.value_bn = nn.BatchNorm2d(HEAD_CHANNELS)
+        self.value_fc1 = nn.Linear(HEAD_CHANNELS * cells, VALUE_HIDDEN)
+        self.value_fc2 = nn.Linear(VALUE_HIDDEN, 1)
+        # Xavier-normal weights, zero biases (neural_network.py:85-92); module order == reference
+        # order so torch.manual_seed(s) gives the same initial weights as the reference
+        for mod in self.modules():
+            if isinstance(mod, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_normal_(mod.weight)
+                if mod.bias is not None:
+                    nn.init.zeros_(mod.bias)
+
+    # ---- forward: logits + tanh value (neural_network.py:94-123)
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        for blk in self.res_blocks:
+            x = blk(x)
+        p = F.relu(self.policy_bn(self.policy_conv(x))).flatten(1)
+        v = F.relu(self.value_bn(self.value_conv(x))).flatten(1)
+        return self.policy_fc(p), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
+
+    # ---- batched evaluation on the module's device
+    @torch.no_grad()
+    def predict_batch(self, planes):
+        """planes float32 [G,5,R,C] on the module's device -> (softmax policy f32 [G,A], value f32 [G])."""
+        self.eval()
+        logits, value = self.forward(planes)
+        return F.softmax(logits, dim=1), value.reshape(-1)
+
+    # ---- single-board API of the reference (neural_network.py:125-154)
+    def predict(self, board):
+        dev = next(self.parameters()).device
+        x = self.board_to_input(board).unsqueeze(0).to(dev)
+        pol, val = self.predict_batch(x)
+        return pol[0].cpu().numpy(), val.cpu().numpy()[0]
+
+    def board_to_input(self, board):
+        """5 planes float32 (neural_network.py:156-196).  On a ROCm device this is the HIP encode
+        kernel; for a CPU module the planes are computed with torch ops on the host."""
+        arr = np.ascontiguousarray(board.get_board(), dtype=np.int8)
+        dev = next(self.parameters()).device
+        if dev.type == "cuda":
+            from . import engine
+            return engine.encode_planes(torch.from_numpy(arr[None]).to(dev))[0]
+        b = torch.from_numpy(arr)
+        n, m = arr.shape
+        occ = (b != 0)
+        rows = (occ.sum(1).double() / m).float()[:, None].expand(n, m)
+        cols = (occ.sum(0).double() / n).float()[None, :].expand(n, m)
+        return torch.stack([(b == 0).float(), (b == 1).float(), (b == -1).float(), rows, cols])
+
+    # ---- checkpoint format of the reference (neural_network.py:198-237)
+    def save_model(self, filename):
+        d = os.path.dirname(filename)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        torch.save({"state_dict": self.state_dict(), "board_size": self.board_size,
+                    "action_size": self.action_size}, filename)
+
+    def load_model(self, filename):
+        if not os.path.exists(filename):
+            raise FileNotFoundError(f"Model file {filename} not found")
+        ckpt = torch.load(filename, map_location="cpu", weights_only=True)
+        self.load_state_dict(ckpt["state_dict"])
+
+
+def fold_batchnorm(conv, bn):
+    """(weight, bias) of the conv with the eval-mode BatchNorm folded in."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = conv.weight * scale.reshape(-1, 1, 1, 1)
+    b = (conv.bias - bn.running_mean) * scale + bn.bias
+    return w.detach(), b.detach()
+
+
+class BatchedEvaluator:
+    """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
+
+    mode "fp32": the module as is (parity path: same arithmetic as predict()).
+    mode "bf16"/"fp16": inference-only fast path -- eval-mode BatchNorm folded into the convs,
+    channels-last activations, reduced-precision MFMA convolutions, softmax/tanh in fp32.
+    """
+
+    def __init__(self, net, mode="fp32"):
+        self.net = net.eval()
+        self.mode = mode
+        self.device = next(net.parameters()).device
+        if mode != "fp32":
+            self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+            self._fold()
+
+    def _fold(self):
+        n, dt = self.net, self.dtype
+        cl = torch.channels_last
+
+        def prep(conv, bn):
+            w, b = fold_batchnorm(conv, bn)
+            return w.to(dt).contiguous(memory_format=cl), b.to(dt)
+
+        self.stem = prep(n.conv1, n.bn1)
+        self.blocks = [(prep(blk.conv1, blk.bn1), prep(blk.conv2, blk.bn2)) for blk in n.res_blocks]
+        self.phead = prep(n.policy_conv, n.policy_bn)
+        self.vhead = prep(n.value_conv, n.value_bn)
+        self.pfc = (n.policy_fc.weight.detach().to(dt), n.policy_fc.bias.detach().to(dt))
+        self.vfc1 = (n.value_fc1.weight.detach().to(dt), n.value_fc1.bias.detach().to(dt))
+        self.vfc2 = (n.value_fc2.weight.detach().float(), n.value_fc2.bias.detach().float())
+
+    @torch.no_grad()
+    def __call__(self, planes):
+        if self.mode == "fp32":
+            return self.net.predict_batch(planes)
+        x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.relu(F.conv2d(x, *self.stem, padding=1))
+        for (c1, c2) in self.blocks:
+            y = F.relu(F.conv2d(x, *c1, padding=1))
+            x = F.relu(F.conv2d(y, *c2, padding=1) + x)
+        p = F.relu(F.conv2d(x, *self.phead)).contiguous().flatten(1)     # NCHW flatten order as the reference
+        v = F.relu(F.conv2d(x, *self.vhead)).contiguous().flatten(1)
+        logits = F.linear(p, *self.pfc).float()
+        h = F.relu(F.linear(v, *self.vfc1)).float()
+        value = torch.tanh(F.linear(h, *self.vfc2)).reshape(-1)
+        return F.softmax(logits, dim=1), value
