@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play hot path benchmark (BASELINE.json metric: self-play positions/s and MCTS
+node-expansions/s at 800 sims on 8x8).
+
+    python bench.py --gpus N --steps K --warmup W          (N=1: plain python; N>1: torchrun)
+
+A "step" = one lockstep MOVE of all G concurrent games = 1 root evaluation + `sims` simulations,
+each simulation being one fused HIP tree kernel + one batched CNN forward over G leaves, then the
+move itself (root policy, sampling, rules step, game-ended test, slot refill).  Workload = config[1]
+of BASELINE.json: 8x8, 800 sims, 4096 concurrent games per GPU, frozen random-init 128x10 net
+(torch.manual_seed(0)); games start at staggered plies from seeded random legal play so the batch
+is in the steady state of continuous self-play.  value = positions/s over all ranks.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--rows", type=int, default=8)
+    ap.add_argument("--cols", type=int, default=8)
+    ap.add_argument("--channels", type=int, default=128)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
+    ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--kernel-timing-steps", type=int, default=64,
+                    help="lockstep steps timed with HIP events for the roofline object")
+    return ap.parse_args()
+
+
+def stagger_start(eng, seed):
+    """Advance game g by (g mod 48) uniformly random legal plies with the HIP rules kernels, so the
+    batch holds openings, middle games and endings like continuous self-play does."""
+    from yinyang_game_alphazero_amd import engine as E
+    G, dev = eng.G, eng.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    target = (torch.arange(G, device=dev) * 7919) % 48
+    boards = torch.zeros((G, eng.R, eng.C), dtype=torch.int8, device=dev)
+    players = torch.ones(G, dtype=torch.int8, device=dev)
+    ply = torch.zeros(G, dtype=torch.int32, device=dev)
+    for _ in range(2 * 48):
+        mask = E.valid_mask(boards, players).to(torch.float32)
+        has = mask.sum(1) > 0
+        adv = (ply < target) & has
+        nomove = (ply < target) & ~has
+        players = torch.where(nomove, -players, players).contiguous()          # pass
+        dist = torch.where(adv[:, None], mask, torch.full_like(mask, 1.0))
+        act = torch.multinomial(dist, 1, generator=gen).reshape(-1).to(torch.int32)
+        act = torch.where(adv, act, torch.full_like(act, -1)).contiguous()
+        old = players.clone()
+        E.step_(boards, players, act)
+        players = torch.where(adv, players, old).contiguous()
+        ply += adv.to(torch.int32)
+    ended = E.game_ended(boards, players) != 0
+    boards[ended] = 0
+    players[ended] = 1
+    ply[ended] = 0
+    eng.boards, eng.players, eng.ply = boards, players.contiguous(), ply
+    eng.alive[:] = True
+    eng.n_ex[:] = 0
+    eng.game_id = torch.arange(G, device=dev, dtype=torch.int64)
+    eng.games_started = G
+    eng.games_target = 1 << 60          # refill forever
+
+
+def hip_event_kernel_time(eng, n_steps):
+    """Average duration of the fused tree kernel (yy_mcts_step) measured with HIP events recorded on
+    the stream the kernel is launched on, through the HIP runtime directly (not torch.cuda.Event)."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    ev_t = ctypes.c_void_p
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ctx, evaluator = eng.ctx, eng.evaluator
+    starts, stops = [], []
+    for _ in range(n_steps):
+        a, b = ev_t(), ev_t()
+        assert hip.hipEventCreate(ctypes.byref(a)) == 0 and hip.hipEventCreate(ctypes.byref(b)) == 0
+        starts.append(a)
+        stops.append(b)
+    # a fresh search so that a select is pending
+    rp = eng.players.contiguous()
+    ctx.begin(eng.boards, rp, None)
+    policy, _ = evaluator(ctx.planes)
+    ctx.expand_root(policy, None, 0.25)
+    ctx.select()
+    ctx.reset_counters()
+    nn_ms = []
+    for i in range(n_steps):
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        policy, value = evaluator(ctx.planes)
+        t1.record()
+        nn_ms.append((t0, t1))
+        assert hip.hipEventRecord(starts[i], stream) == 0
+        ctx.step(policy, value)
+        assert hip.hipEventRecord(stops[i], stream) == 0
+    torch.cuda.synchronize()
+    ms = ctypes.c_float(0)
+    tot = 0.0
+    for a, b in zip(starts, stops):
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        tot += ms.value
+        hip.hipEventDestroy(a)
+        hip.hipEventDestroy(b)
+    counters = ctx.status()
+    policy, value = evaluator(ctx.planes)
+    ctx.expand_backup(policy, value)
+    nn = sum(a.elapsed_time(b) for a, b in nn_ms) / n_steps
+    return tot / n_steps, nn, counters
+
+
+def algorithmic_bytes(counters, G, A, n_steps, nw):
+    """bytes = 16*sum_levels(k) + 2*Bb + Mb + 8 + 20*A + 4*A + 4 + 16*k_leaf
+    + 16*(d+1) + 32 per expansion, from the measured device counters."""
+    ev = max(counters["evals"], 1)
+    Bb, Mb = 16 * nw, 8 * nw
+    per_exp = 2 * Bb + Mb + 8 + 20 * A + 4 * A + 4 + 32
+    total = (16 * counters["children_scanned"] + per_exp * counters["evals"] + 16 * counters["children_created"]
+             + 16 * (counters["levels"] + n_steps * G))
+    return total / n_steps, dict(mean_children_scanned=counters["children_scanned"] / (n_steps * G),
+                                 mean_depth=counters["levels"] / (n_steps * G),
+                                 mean_k_leaf=counters["children_created"] / ev,
+                                 eval_fraction=counters["evals"] / (n_steps * G),
+                                 bytes_per_expansion=total / ev)
+
+
+def cpu_baseline(args):
+    """The CPU restatement (oracle/yy_oracle.c: same float32 PUCT, copied semantics) driving the same
+    network under PyTorch CPU, batch 1 like the reference (self_play.py:54-59), timed on this host for
+    a bounded sample: repeated `sims`-simulation searches from the empty board until ~cpu_seconds."""
+    import oracle_lib as O
+    from yinyang_game_alphazero_amd.game import YinYangGame
+    from yinyang_game_alphazero_amd.network import YinYangNeuralNetwork
+    torch.manual_seed(0)
+    net = YinYangNeuralNetwork(YinYangGame(args.rows, args.cols), args.channels, args.blocks).eval()
+    cores = torch.get_num_threads()
+    enc = O.encode_planes
+
+    def predict(board):
+        x = torch.from_numpy(enc(np.ascontiguousarray(board)[None]))
+        with torch.no_grad():
+            logits, v = net(x)
+            p = torch.softmax(logits, 1)
+        return p[0].numpy(), float(v[0, 0])
+
+    sims = min(args.sims, 200)
+    t0 = time.perf_counter()
+    evals = 0
+    n = 0
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        r = O.search_callback(np.zeros((args.rows, args.cols), np.int8), 1, sims, 1, predict)
+        evals += r.n_evals + 1
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": evals / dt, "unit": "expansions/s", "cores": cores, "kind": "port",
+            "sample": f"{n} searches x {sims} sims from the empty {args.rows}x{args.cols} board, batch-1 fp32 "
+                      f"{args.channels}x{args.blocks} net on torch CPU ({cores} threads), oracle/yy_oracle.c tree",
+            "positions_per_s": evals / dt / (args.sims + 1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, gather_examples
+
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(args.rows, args.cols)
+    net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
+    evaluator = pkg.BatchedEvaluator(net, args.nn)
+    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=args.games,
+                         board_semantics=args.semantics, reference_quirks=args.quirks,
+                         use_graph=not args.no_graph, seed=1000 + rank, device=dev,
+                         first_game_index=rank, game_index_stride=world)
+    stagger_start(eng, 4242 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.play_move()
+    eng.collect()
+    eng.ctx.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    positions = 0
+    for _ in range(args.steps):
+        positions += eng.play_move()
+    barrier()
+    dt = time.perf_counter() - t0
+    counters = eng.ctx.status()
+    ex = eng.collect()
+    # the single exchange of the path: all-gather the examples produced in the timed region
+    tg0 = time.perf_counter()
+    ex_all = gather_examples(ex)
+    torch.cuda.synchronize()
+    gather_s = time.perf_counter() - tg0
+    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt = float(mx[2])
+    positions_all, evals_all = float(tot[0]), float(tot[1])
+
+    roof = cpub = None
+    extra = {}
+    if rank == 0:
+        k_ms, nn_ms, kc = hip_event_kernel_time(eng, args.kernel_timing_steps)
+        nw = (args.rows * args.cols + 63) // 64
+        bytes_per_launch, shape = algorithmic_bytes(kc, args.games, args.rows * args.cols, args.kernel_timing_steps, nw)
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_launch, **shape}
+        A = args.rows * args.cols
+        Cc = args.channels
+        flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
+                      + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
+        extra = {"nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
+                 "tree_kernel_ms": k_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
+        if not args.no_cpu_baseline:
+            cpub = cpu_baseline(args)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        sims_total = args.steps * args.sims * args.games * world
+        line = {
+            "metric": "self-play positions/sec (+ MCTS node-expansions/sec) at 800 sims, 8x8 board",
+            "value": positions_all / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.nn, "data": "synthetic",
+            "expansions_per_s": evals_all / dt, "simulations_per_s": sims_total / dt,
+            "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
+                                   f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
+                                   f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
+                       "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
+                       "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
+            "roofline": roof, "cpu_baseline": cpub, **extra,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

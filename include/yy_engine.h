@@ -120,7 +120,8 @@ int yy_mcts_begin(yy_mcts *ctx, const int8_t *boards, const int8_t *root_players
 /* Root expansion (mcts.py:297-317).  policy float32 [G,A] = softmax output of call #0 (the value
  * is discarded by the reference).  noise: NULL, or float64 [G,A] holding each game's Dirichlet
  * draw scattered to its legal action indices; priors become
- * f32( f64(f32(1-eps) * p) + eps*noise )  exactly as mcts.py:310-312 evaluates under numpy 2. */
+ * f32( f64(f32(1-eps) * p) + eps*noise )  exactly as mcts.py:310-312 evaluates under numpy 2.
+ * A game whose noise row is all zero keeps its raw priors (add_exploration_noise=False). */
 int yy_mcts_expand_root(yy_mcts *ctx, const float *policy, const double *noise, double eps,
                         yy_stream_t stream);
 

@@ -727,13 +727,26 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
             const int k = bb_popc(mask);
             if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = 1; st->leaf_kind = K_NONE; } return; }
             const float keep = (float)(1.0 - d.eps);
+            // a game whose noise row is all zero over its legal moves drew no noise (a Dirichlet draw
+            // sums to 1): it keeps the raw priors, like add_exploration_noise=False (mcts.py:298)
+            bool mix = false;
+            if (noise) {
+                uint64_t any = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    const int cell = j * 64 + lane;
+                    const bool nz = ((mask.w[j] >> lane) & 1) && noise[(size_t)g * A + cell] != 0.0;
+                    any |= __ballot(nz);
+                }
+                mix = any != 0;
+            }
             int base = n_edges;
 #pragma unroll
             for (int j = 0; j < NW; j++) {
                 const int cell = j * 64 + lane;
                 if ((mask.w[j] >> lane) & 1) {
                     float p = policy[(size_t)g * A + cell];
-                    if (noise) {                                                    // mcts.py:310-312
+                    if (mix) {                                                      // mcts.py:310-312
                         const float kp = __fmul_rn(keep, p);
                         p = (float)__dadd_rn((double)kp, __dmul_rn(d.eps, noise[(size_t)g * A + cell]));
                     }

@@ -1,0 +1,437 @@
+"""Self-play: the batched lockstep engine (throughput path) and the reference's self-play API.
+
+Reference: src/yin_yang/ai/self_play.py -- SelfPlayWorker.play_game :72-192, generate_games
+:194-216, SelfPlayManager :218-335, generate_self_play_data :337-387.
+
+`SelfPlayEngine` is the MI355X design: G games advance in lockstep on one GPU; per move every
+game runs `num_simulations` simulations, each simulation being ONE fused HIP kernel
+(expand+backup of the previous leaves, PUCT select + rules + plane encode of the next) and ONE
+batched CNN forward over all G leaves, replayed from a hipGraph.  Finished games are replaced in
+their slot so the batch stays full.  Episodes shard across ranks (one process per GPU) and the
+(state, pi, z) examples are collected with one all-gather at the end (`gather_examples`).
+
+`SelfPlayWorker` / `SelfPlayManager` / `generate_self_play_data` keep the reference's names and
+signatures.  `reference_quirks=True` reproduces Q4/Q5 of SURVEY.md (always search and mask as
+player +1, never alternate the value labels); `board_semantics="aliased"` reproduces Q2.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import engine
+from .game import YinYangGame, YinYangLogic
+from .mcts import MCTS
+from .network import BatchedEvaluator, YinYangNeuralNetwork
+
+DRAW = 1e-4
+
+
+# =============================================================================== graph-replayed search
+class LockstepSearch:
+    """MCTS.search for G games with the simulation loop replayed from a hipGraph.
+
+    One graph = [evaluator forward on ctx.planes] + [yy_mcts_step]; everything in it is enqueued on
+    the capture stream (the C ABI takes the stream as an argument), so a replay costs one host call
+    instead of ~60 kernel launches."""
+
+    def __init__(self, ctx, evaluator, use_graph=True, eager_sims=3):
+        self.ctx, self.evaluator, self.use_graph = ctx, evaluator, use_graph
+        self.eager_sims = eager_sims
+        self.graph = None
+
+    def _sim_step(self):
+        policy, value = self.evaluator(self.ctx.planes)
+        self.ctx.step(policy, value)
+
+    def run(self, boards, root_players, num_sims, noise=None, eps=0.25, active=None):
+        ctx = self.ctx
+        ctx.begin(boards, root_players, active)
+        policy, _ = self.evaluator(ctx.planes)                 # mcts.py:295, value discarded
+        ctx.expand_root(policy, noise, eps)
+        ctx.select()
+        done = 0
+        n_fused = num_sims - 1
+        if self.use_graph and self.graph is None and n_fused > self.eager_sims:
+            for _ in range(self.eager_sims):                   # warm-up (MIOpen algo search etc.) = real sims
+                self._sim_step()
+                done += 1
+            torch.cuda.synchronize(ctx.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._sim_step()
+            self.graph = g
+        while done < n_fused:
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._sim_step()
+            done += 1
+        policy, value = self.evaluator(ctx.planes)             # last simulation: no further select
+        ctx.expand_backup(policy, value)
+
+
+# =============================================================================== batched engine
+class SelfPlayEngine:
+    def __init__(self, game, evaluator, num_simulations=800, concurrent_games=4096, cpuct=1.0,
+                 dirichlet_alpha=0.3, dirichlet_epsilon=0.25, temperature_threshold=10,
+                 board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
+                 device=None, first_game_index=0, game_index_stride=1):
+        assert board_semantics in ("aliased", "copied")
+        self.game = game
+        self.R, self.C = game.getBoardSize()
+        self.A = self.R * self.C
+        self.G = int(concurrent_games)
+        self.sims = int(num_simulations)
+        self.alpha, self.eps = float(dirichlet_alpha), float(dirichlet_epsilon)
+        self.thr = int(temperature_threshold)
+        self.aliased = board_semantics == "aliased"
+        self.quirks = bool(reference_quirks)
+        self.rowcol = bool(getattr(game, "rowcol_rule", False))
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.evaluator = evaluator
+        self.ctx = engine.BatchedMCTS(self.G, self.R, self.C, self.sims, cpuct=cpuct, aliased=self.aliased,
+                                      rowcol=self.rowcol, device=self.device)
+        self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self.first_game_index, self.stride = int(first_game_index), int(game_index_stride)
+        # a game has at most A placements; passes never add examples.  Literal quirk mode can make
+        # no-op moves (illegal placements), so leave generous room there.
+        self.T = self.A + 2 if not self.quirks else 4 * self.A + 8
+        dev, G, T = self.device, self.G, self.T
+        self.boards = torch.zeros((G, self.R, self.C), dtype=torch.int8, device=dev)
+        self.players = torch.ones(G, dtype=torch.int8, device=dev)
+        self.ply = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.n_ex = torch.zeros(G, dtype=torch.int64, device=dev)
+        self.alive = torch.zeros(G, dtype=torch.bool, device=dev)
+        self.game_id = torch.full((G,), -1, dtype=torch.int64, device=dev)
+        self.hist_state = torch.zeros((G, T, self.R, self.C), dtype=torch.int8, device=dev)
+        self.hist_pi = torch.zeros((G, T, self.A), dtype=torch.float32, device=dev)
+        self.hist_player = torch.zeros((G, T), dtype=torch.int8, device=dev)
+        self.out = []          # finished examples: tuples of device tensors
+        self.games_started = 0
+        self.games_finished = 0
+        self.games_target = 0
+        self.positions = 0
+        self._ar = torch.arange(G, device=dev)
+
+    # ---- slots
+    def _start_games(self, slots):
+        n = int(slots.numel())
+        if n == 0:
+            return
+        ids = self.first_game_index + (self.games_started + torch.arange(n, device=self.device)) * self.stride
+        self.games_started += n
+        self.boards[slots] = 0
+        self.players[slots] = 1                       # black starts (self_play.py:81)
+        self.ply[slots] = 0
+        self.n_ex[slots] = 0
+        self.alive[slots] = True
+        self.game_id[slots] = ids
+
+    def _finalize(self, over, result, final_player):
+        """Label and emit the examples of the games in `over` (self_play.py:114-121, 170-188), then
+        refill their slots."""
+        idx = over.nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
+            return
+        n = self.n_ex[idx]
+        sel = torch.arange(self.T, device=self.device)[None, :] < n[:, None]          # [k,T]
+        res = result[idx].to(torch.float64)
+        if self.quirks:
+            z = res[:, None].expand(-1, self.T)                                          # Q5: never alternates
+        else:
+            same = self.hist_player[idx] == final_player[idx][:, None]
+            z = torch.where(same, res[:, None], -res[:, None])
+        states = self.hist_state[idx]
+        if self.quirks and self.aliased:
+            states = self.boards[idx][:, None].expand(-1, self.T, -1, -1)               # Q5: all alias the final board
+        gid = self.game_id[idx][:, None].expand(-1, self.T)
+        plyi = torch.arange(self.T, device=self.device)[None, :].expand(idx.numel(), -1)
+        self.out.append((states[sel], self.hist_pi[idx][sel], z[sel].to(torch.float32), gid[sel], plyi[sel]))
+        self.games_finished += int(idx.numel())
+        self.alive[idx] = False
+        self.game_id[idx] = -1
+        room = max(0, self.games_target - self.games_started)
+        self._start_games(idx[:room])
+
+    # ---- one lockstep move for every live game (self_play.py:91-192)
+    def play_move(self):
+        dev, G = self.device, self.G
+        ones = torch.ones(G, dtype=torch.int8, device=dev)
+        pending = self.alive.clone()
+        searching = torch.zeros(G, dtype=torch.bool, device=dev)
+        passes = torch.zeros(G, dtype=torch.int32, device=dev)
+        for _ in range(2):                                                     # pass handling :103-125
+            rp = ones if self.quirks else self.players                         # Q4
+            has = engine.valid_mask(self.boards, rp.contiguous(), self.rowcol).bool().any(1)
+            go = pending & has
+            searching |= go
+            pending &= ~go
+            nomove = pending & ~has
+            passes += nomove.to(torch.int32)
+            over = nomove & (passes >= 2)
+            if bool(over.any()):
+                r = engine.game_ended(self.boards, self.players, self.rowcol)
+                r = torch.where(r == 0, torch.full_like(r, DRAW), r)           # :110-112
+                self._finalize(over, r, self.players)
+                pending &= ~over
+            flip = nomove & ~over
+            self.players = torch.where(flip, -self.players, self.players)
+        searching &= self.alive
+        if not bool(searching.any()):
+            return 0
+        rp = (ones if self.quirks else self.players).contiguous()
+        mask = engine.valid_mask(self.boards, rp, self.rowcol).to(torch.float64)
+        active = searching.to(torch.uint8)
+        noise = None
+        first = searching & (self.ply == 0)                                    # add_noise = (step == 0), :131
+        if self.eps > 0 and bool(first.any()):
+            gam = torch._standard_gamma(torch.full((G, self.A), self.alpha, dtype=torch.float64, device=dev),
+                                        generator=self.gen) * mask
+            noise = torch.where(first[:, None], gam / gam.sum(1, keepdim=True).clamp_min(1e-300), torch.zeros_like(gam))
+            noise = noise.contiguous()
+        self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=active)
+        pi = self.ctx.root_policy()                                            # T == 1 distribution, :329
+        # ---- record the example before the move (:140)
+        slot = self.n_ex.clamp_max(self.T - 1)
+        ar = self._ar
+        s_idx = ar[searching]
+        self.hist_state[s_idx, slot[s_idx]] = self.boards[s_idx]
+        self.hist_pi[s_idx, slot[s_idx]] = pi[s_idx].to(torch.float32)
+        self.hist_player[s_idx, slot[s_idx]] = self.players[s_idx]
+        self.n_ex += searching.to(torch.int64)
+        # ---- choose the action (:143-160)
+        probs = pi * mask
+        s = probs.sum(1, keepdim=True)
+        uniform = mask / mask.sum(1, keepdim=True).clamp_min(1.0)
+        probs = torch.where(s > 0, probs / s.clamp_min(1e-300), uniform)
+        best = (pi == pi.max(1, keepdim=True).values).to(torch.float64)
+        dist = torch.where((self.ply < self.thr)[:, None], probs, best)
+        dist = torch.where(searching[:, None], dist, torch.full_like(dist, 1.0 / self.A))
+        action = torch.multinomial(dist.to(torch.float32), 1, generator=self.gen).reshape(-1).to(torch.int32)
+        action = torch.where(searching, action, torch.full_like(action, -1))
+        # ---- make the move (:163); aliased: the search has mutated the game's board (Q2)
+        if self.aliased:
+            self.boards = torch.where(searching[:, None, None], self.ctx.boards(), self.boards)
+        old_players = self.players.clone()
+        engine.step_(self.boards, self.players, action.contiguous(), self.rowcol)
+        self.players = torch.where(searching, self.players, old_players)
+        self.ply += searching.to(torch.int32)
+        ended = engine.game_ended(self.boards, self.players, self.rowcol)      # :167
+        n_pos = int(searching.sum())
+        self.positions += n_pos
+        self._finalize(searching & (ended != 0), ended, self.players)
+        return n_pos
+
+    def run(self, num_games, progress=None):
+        """Play `num_games` games to completion; returns the examples (device tensors)."""
+        self.games_target = self.games_started + int(num_games)
+        free = (~self.alive).nonzero(as_tuple=True)[0]
+        self._start_games(free[: int(num_games)])
+        moves = 0
+        while bool(self.alive.any()):
+            self.play_move()
+            moves += 1
+            if progress and moves % 10 == 0:
+                progress(self)
+        self.ctx.status()
+        return self.collect()
+
+    def collect(self):
+        out, self.out = self.out, []
+        if not out:
+            e = torch.empty
+            return dict(states=e((0, self.R, self.C), dtype=torch.int8, device=self.device),
+                        policies=e((0, self.A), dtype=torch.float32, device=self.device),
+                        values=e((0,), dtype=torch.float32, device=self.device),
+                        game_id=e((0,), dtype=torch.int64, device=self.device),
+                        ply=e((0,), dtype=torch.int64, device=self.device))
+        cat = [torch.cat([o[i] for o in out]) for i in range(5)]
+        return dict(states=cat[0], policies=cat[1], values=cat[2], game_id=cat[3], ply=cat[4])
+
+    def close(self):
+        self.ctx.close()
+
+
+# =============================================================================== multi-GPU gather
+def gather_examples(ex, group=None):
+    """One exchange at iteration end: all_gather of the example counts, then all_gather of the padded
+    (state, pi, z) tensors (RCCL over xGMI on GPUs; gloo on CPU tensors in the tests).  Equivalent of
+    the return_queue.get loop (self_play.py:311-315).  Every rank returns the concatenation in rank
+    order."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return ex
+    world = dist.get_world_size(group)
+    dev = ex["states"].device
+    n = torch.tensor([ex["states"].shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c) for c in counts]
+    n_max = max(counts + [1])
+    out = {}
+    for key, t in ex.items():
+        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        pad[: t.shape[0]] = t
+        buf = torch.empty((world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(buf, pad, group=group)
+        out[key] = torch.cat([buf[r * n_max: r * n_max + counts[r]] for r in range(world)])
+    return out
+
+
+# =============================================================================== reference API
+class SelfPlayWorker:
+    """self_play.py:22-216 with the same constructor; plays games one at a time through MCTS (G == 1)
+    drawing from the global numpy stream exactly where the reference does, so identical seeds give
+    identical transcripts.  Defaults reproduce the literal reference (aliased boards, quirks)."""
+
+    def __init__(self, game, model_path, num_simulations=800, num_games=1, temperature_threshold=10,
+                 dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0, num_parallel=1,
+                 board_semantics="aliased", reference_quirks=True, neural_net=None, device=None):
+        self.game, self.model_path = game, model_path
+        self.num_simulations, self.num_games = num_simulations, num_games
+        self.temperature_threshold = temperature_threshold
+        self.dirichlet_alpha, self.dirichlet_epsilon, self.cpuct = dirichlet_alpha, dirichlet_epsilon, cpuct
+        self.num_parallel = num_parallel
+        self.board_semantics, self.reference_quirks = board_semantics, reference_quirks
+        if neural_net is None:
+            neural_net = YinYangNeuralNetwork(game)
+            if os.path.exists(model_path):
+                neural_net.load_model(model_path)
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            neural_net = neural_net.to(dev).eval()    # the reference keeps self-play inference on the CPU (:54-59)
+        self.neural_net = neural_net
+        self.mcts = MCTS(game, neural_net, num_simulations=num_simulations, cpuct=cpuct,
+                         dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon,
+                         num_threads=num_parallel, board_semantics=board_semantics, device=device)
+
+    def play_game(self):
+        game, examples = self.game, []
+        board = game.getInitBoard()
+        player, step, passes = 1, 0, 0
+        copied = self.board_semantics == "copied"
+
+        def label(result):
+            out, value = [], result
+            for i, (b, pi, pl) in enumerate(examples):
+                if self.reference_quirks:
+                    out.append((b, pi, value if i % 2 == 0 else -value))      # :116-118 (nets out to +result)
+                    value = -value
+                else:
+                    out.append((b, pi, result if pl == player else -result))
+            return out
+
+        while True:
+            temperature = 1.0 if step < self.temperature_threshold else 0
+            root_player = 1 if self.reference_quirks else player               # Q4
+            valid_moves = game.getValidMoves(board, root_player)
+            valid_idx = np.where(valid_moves == 1)[0]
+            if len(valid_idx) == 0:
+                passes += 1
+                if passes >= 2:
+                    result = game.getGameEnded(board, player)
+                    if result == 0:
+                        result = DRAW
+                    return label(result)
+                player = -player
+                continue
+            passes = 0
+            pi, _root = self.mcts.search(board, root_player, add_exploration_noise=(step == 0))
+            examples.append((board, pi, player))
+            if temperature == 0:
+                action = np.random.choice(np.where(pi == np.max(pi))[0])
+            else:
+                probs = pi * valid_moves
+                if np.sum(probs) > 0:
+                    probs = probs / np.sum(probs)
+                else:
+                    probs = np.zeros_like(valid_moves)
+                    probs[valid_idx] = 1.0 / len(valid_idx)
+                action = np.random.choice(len(probs), p=probs)
+            if copied:                                                         # examples keep the pre-move board
+                nb = YinYangLogic(board.n, board.m, getattr(board, "rowcol_rule", False))
+                nb.board = board.board.copy()
+                board = nb
+            board, player = game.getNextState(board, player, action)
+            step += 1
+            result = game.getGameEnded(board, player)
+            if result != 0:
+                return label(result)
+
+    def generate_games(self):
+        all_examples = []
+        for _ in range(self.num_games):
+            all_examples.extend(self.play_game())
+        return all_examples
+
+
+class SelfPlayManager:
+    """self_play.py:218-335.  The reference forks `num_workers` CPU processes and pickles lists back
+    through a queue; here `num_workers * games_per_worker` episodes are sharded over the ranks of the
+    running job (one process per GPU, `torchrun`), each rank plays its shard on the batched engine,
+    and one all-gather collects the examples."""
+
+    def __init__(self, game, model_path, num_workers=1, num_simulations=800, games_per_worker=1,
+                 temperature_threshold=10, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0,
+                 mcts_parallel=1, concurrent_games=4096, board_semantics="copied", reference_quirks=False,
+                 nn_mode="bf16", seed=0, num_channels=128, num_res_blocks=10):
+        self.game, self.model_path = game, model_path
+        self.num_workers, self.games_per_worker = num_workers, games_per_worker
+        self.num_simulations, self.temperature_threshold = num_simulations, temperature_threshold
+        self.dirichlet_alpha, self.dirichlet_epsilon, self.cpuct = dirichlet_alpha, dirichlet_epsilon, cpuct
+        self.mcts_parallel = mcts_parallel
+        self.concurrent_games, self.board_semantics, self.reference_quirks = concurrent_games, board_semantics, reference_quirks
+        self.nn_mode, self.seed = nn_mode, seed
+        self.num_channels, self.num_res_blocks = num_channels, num_res_blocks
+        self.stats = {}
+
+    def generate_games_parallel(self):
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+        total = self.num_workers * self.games_per_worker
+        mine = total // world + (1 if rank < total % world else 0)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        net = YinYangNeuralNetwork(self.game, self.num_channels, self.num_res_blocks)
+        if os.path.exists(self.model_path):
+            net.load_model(self.model_path)       # every rank reads the same file: no broadcast needed
+        net = net.to(dev).eval()
+        eng = SelfPlayEngine(self.game, BatchedEvaluator(net, self.nn_mode), num_simulations=self.num_simulations,
+                             concurrent_games=max(1, min(self.concurrent_games, mine)), cpuct=self.cpuct,
+                             dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
+                             temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
+                             reference_quirks=self.reference_quirks, seed=self.seed * 1000003 + rank,
+                             first_game_index=rank, game_index_stride=world, device=dev)
+        t0 = time.perf_counter()
+        ex = eng.run(mine) if mine > 0 else eng.collect()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        counters = eng.ctx.status()
+        ex = gather_examples(ex)
+        self.stats = dict(seconds=t1 - t0, positions=eng.positions, games=eng.games_finished, **counters)
+        eng.close()
+        return ex
+
+
+def generate_self_play_data(game, model_path, output_dir, num_games=100, num_workers=1, num_simulations=800,
+                            **engine_kwargs):
+    """self_play.py:337-387: same arguments and the same file name pattern.  The .npz holds plain
+    tensors (`states` int8 [N,R,C], `policies` float64 [N,A], `values` float64 [N]; `boards` is an
+    alias of `states`) instead of pickled board objects."""
+    os.makedirs(output_dir, exist_ok=True)
+    games_per_worker = max(1, num_games // num_workers)               # :355 (remainder dropped)
+    manager = SelfPlayManager(game, model_path, num_workers=num_workers, games_per_worker=games_per_worker,
+                              num_simulations=num_simulations, **engine_kwargs)
+    ex = manager.generate_games_parallel()
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}.npz")
+    if rank == 0:
+        states = ex["states"].cpu().numpy()
+        np.savez(filename, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
+                 values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),
+                 ply=ex["ply"].cpu().numpy())
+    generate_self_play_data.last_stats = manager.stats
+    return filename
