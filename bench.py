@@ -156,6 +156,9 @@ def cpu_baseline(args):
     from yinyang_game_alphazero_amd.network import YinYangNeuralNetwork
     torch.manual_seed(0)
     net = YinYangNeuralNetwork(YinYangGame(args.rows, args.cols), args.channels, args.blocks).eval()
+    # the GPU box gives one GPU's share of the host: 16 cores (intra-op threads beyond that only add
+    # contention for batch-1 convolutions)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cores = torch.get_num_threads()
     enc = O.encode_planes
 

@@ -163,6 +163,15 @@ int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
 int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
 int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);
 
+/* ------------------------------------------------------------------ evaluator epilogue
+ * Batched leaf evaluator fast path (the reference evaluates one board per call:
+ * ai/neural_network.py:94-123, 125-154).  In-place fused epilogue of one convolution of the tower
+ * on a channels-last bf16 activation tensor x [rows, C] (rows = G*R*Cb cells):
+ *     x = relu?( x + bias[c] (+ residual) )         bias float32 [C]; residual bf16 [rows, C] or NULL
+ * (eval-mode BatchNorm is folded into the convolution weights and this bias on the host). */
+int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C,
+                        int relu, yy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+"""GPU: the evaluator fast path.  Floating point, so tolerance-based (written in each test):
+the fused HIP epilogue against plain torch ops (bf16 rounding: 1 ulp of bf16 = 2^-8 relative), and
+the bf16 tower against the fp32 module (policy abs 2e-2, value abs 5e-2: random-init 128x10 net)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bias_act_matches_torch():
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(0)
+    for (N, C, H, W) in ((37, 128, 8, 8), (5, 32, 12, 12), (3, 8, 1, 1)):
+        x = torch.randn(N, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(N, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(C, device="cuda")
+        for res in (None, r):
+            for relu in (True, False):
+                want = x.float() + b.reshape(1, C, 1, 1) + (0 if res is None else res.float())
+                if relu:
+                    want = want.clamp_min(0)
+                got = pkg.engine.bias_act_(x.clone(memory_format=torch.channels_last), b, res, relu).float()
+                # one bf16 rounding of the exact f32 result
+                assert torch.equal(got, want.to(torch.bfloat16).float())
+
+
+def test_bf16_tower_close_to_fp32_module():
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(8, 8)
+    net = pkg.YinYangNeuralNetwork(game).cuda().eval()
+    rng = np.random.default_rng(1)
+    boards = torch.from_numpy(rng.integers(-1, 2, size=(64, 8, 8)).astype(np.int8)).cuda()
+    planes = pkg.engine.encode_planes(boards)
+    p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+    for fused in (True, False):
+        p16, v16 = pkg.BatchedEvaluator(net, "bf16", fused_epilogue=fused)(planes)
+        assert p16.dtype == torch.float32 and v16.shape == (64,)
+        assert float((p16 - p32).abs().max()) < 2e-2
+        assert float((v16 - v32).abs().max()) < 5e-2
+        assert torch.allclose(p16.sum(1), torch.ones(64, device="cuda"), atol=1e-4)
+
+
+def test_fp32_module_matches_cpu_module():
+    """same nn.Module on the GPU and on the CPU: policy/value within 1e-4 abs (torch conv/BN)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(6, 6)
+    net = pkg.YinYangNeuralNetwork(game, 32, 2).eval()
+    rng = np.random.default_rng(2)
+    b = rng.integers(-1, 2, size=(16, 6, 6)).astype(np.int8)
+    import oracle_lib as O
+    planes = torch.from_numpy(O.encode_planes(b))
+    pc, vc = net.predict_batch(planes)
+    pg, vg = net.cuda().predict_batch(planes.cuda())
+    assert float((pg.cpu() - pc).abs().max()) < 1e-4 and float((vg.cpu() - vc).abs().max()) < 1e-4

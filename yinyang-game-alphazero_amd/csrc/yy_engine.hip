@@ -1073,3 +1073,80 @@ extern "C" int yy_mcts_reset_counters(yy_mcts *c, yy_stream_t s) {
     HIP_TRY(hipGetLastError());
     return YY_OK;
 }
+
+// =============================================================================== evaluator epilogue
+// Fused bias + residual + ReLU over a channels-last bf16 activation tensor, in place:
+//     x[r, c] = relu( x[r, c] + bias[c] (+ residual[r, c]) )
+// This replaces the 3-4 separate elementwise passes PyTorch/MIOpen run after every convolution of
+// the policy/value tower (bias add, residual add, clamp) by ONE pass: 16-B loads/stores per lane,
+// f32 arithmetic, one bf16 rounding.  HBM-bound: (2 or 3) * rows * C * 2 bytes per launch.
+typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round-to-nearest-even, NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool HAS_RES, bool RELU, bool FIXED>
+__global__ void __launch_bounds__(256) k_bias_act(us8 *x, const float *bias, const us8 *res, size_t n_vec, int cvec) {
+    // cvec = C / 8 vectors per row.  FIXED: the grid stride is a multiple of cvec, so a lane keeps the
+    // same 8 channels for its whole grid-stride walk and the bias slice lives in registers.
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float b[8];
+    if (FIXED) {
+        const float4 *bp = reinterpret_cast<const float4 *>(bias + (tid % (size_t)cvec) * 8);
+        const float4 b0 = bp[0], b1 = bp[1];
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
+        b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+    }
+    for (size_t i = tid; i < n_vec; i += stride) {
+        if (!FIXED) {
+            const int cb = (int)(i % (size_t)cvec) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) b[j] = bias[cb + j];
+        }
+        const us8 v = x[i];
+        us8 r;
+        if (HAS_RES) r = res[i];
+        us8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float f = bf2f(v[j]) + b[j];
+            if (HAS_RES) f += bf2f(r[j]);
+            if (RELU) f = fmaxf(f, 0.0f);
+            o[j] = f2bf(f);
+        }
+        x[i] = o;
+    }
+}
+
+template <bool FIXED>
+static void launch_bias_act(us8 *xv, const float *bias, const us8 *rv, size_t n_vec, int cvec, int relu, unsigned blocks,
+                            hipStream_t st) {
+    if (rv) {
+        if (relu) k_bias_act<true, true, FIXED><<<dim3(blocks), dim3(256), 0, st>>>(xv, bias, rv, n_vec, cvec);
+        else k_bias_act<true, false, FIXED><<<dim3(blocks), dim3(256), 0, st>>>(xv, bias, rv, n_vec, cvec);
+    } else {
+        if (relu) k_bias_act<false, true, FIXED><<<dim3(blocks), dim3(256), 0, st>>>(xv, bias, rv, n_vec, cvec);
+        else k_bias_act<false, false, FIXED><<<dim3(blocks), dim3(256), 0, st>>>(xv, bias, rv, n_vec, cvec);
+    }
+}
+
+extern "C" int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C, int relu,
+                                   yy_stream_t s) {
+    if (rows == 0) return YY_OK;
+    if (!x || !bias || rows < 0 || C <= 0) return set_err(YY_E_INVALID, "bad argument%s%s");
+    if (C % 8) return set_err(YY_E_UNSUPPORTED, "channels must be a multiple of 8%s%s");
+    const int cvec = C / 8;
+    const size_t n_vec = (size_t)rows * (size_t)cvec;
+    size_t blocks = (n_vec + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;          // ~8 blocks per CU, grid-stride the rest
+    const bool fixed = (256 % cvec) == 0;            // grid stride (blocks*256) is then a multiple of cvec
+    if (fixed) launch_bias_act<true>((us8 *)x, bias, (const us8 *)residual, n_vec, cvec, relu, (unsigned)blocks, (hipStream_t)s);
+    else launch_bias_act<false>((us8 *)x, bias, (const us8 *)residual, n_vec, cvec, relu, (unsigned)blocks, (hipStream_t)s);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}

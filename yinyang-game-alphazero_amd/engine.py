@@ -120,6 +120,22 @@ def mask_terminal_bb(black, white, R, Cc, rowcol=False, out=None):
     return m1, m2, res
 
 
+def bias_act_(x, bias, residual=None, relu=True):
+    """In-place fused epilogue on a channels-last bf16 activation tensor [N,C,H,W] (NHWC memory):
+    x = relu?(x + bias[c] (+ residual)).  One HIP pass (csrc k_bias_act)."""
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.bfloat16 or not x.is_cuda:
+        raise _lib.YYError(-1, "bias_act_: expected a channels-last bf16 device tensor [N,C,H,W]")
+    N, Cc, H, W = x.shape
+    if bias.dtype != torch.float32 or bias.numel() != Cc or not bias.is_cuda:
+        raise _lib.YYError(-1, "bias_act_: bias must be float32 [C] on the device")
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.YYError(-1, "bias_act_: residual must match x (channels-last bf16)")
+    with torch.cuda.device(x.device):
+        check(lib().yy_nn_bias_act_bf16(_p(x), _p(bias), _p(residual), N * H * W, Cc, int(bool(relu)), _stream()))
+    return x
+
+
 # ------------------------------------------------------------------ batched MCTS context
 class BatchedMCTS:
     """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate

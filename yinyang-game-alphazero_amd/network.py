@@ -130,13 +130,17 @@ class BatchedEvaluator:
 
     mode "fp32": the module as is (parity path: same arithmetic as predict()).
     mode "bf16"/"fp16": inference-only fast path -- eval-mode BatchNorm folded into the convs,
-    channels-last activations, reduced-precision MFMA convolutions, softmax/tanh in fp32.
+    channels-last activations, reduced-precision MFMA convolutions (MIOpen implicit GEMM), softmax/tanh
+    in fp32.  In bf16 mode with `fused_epilogue` (default) every convolution is issued WITHOUT bias and
+    followed by ONE hand-written HIP pass (csrc k_bias_act: bias + residual + ReLU in place) instead of
+    the 3-4 elementwise kernels PyTorch would launch.
     """
 
-    def __init__(self, net, mode="fp32"):
+    def __init__(self, net, mode="fp32", fused_epilogue=True):
         self.net = net.eval()
         self.mode = mode
         self.device = next(net.parameters()).device
+        self.fused = bool(fused_epilogue) and mode == "bf16"
         if mode != "fp32":
             self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
             self._fold()
@@ -147,7 +151,7 @@ class BatchedEvaluator:
 
         def prep(conv, bn):
             w, b = fold_batchnorm(conv, bn)
-            return w.to(dt).contiguous(memory_format=cl), b.to(dt)
+            return w.to(dt).contiguous(memory_format=cl), (b.float().contiguous() if self.fused else b.to(dt))
 
         self.stem = prep(n.conv1, n.bn1)
         self.blocks = [(prep(blk.conv1, blk.bn1), prep(blk.conv2, blk.bn2)) for blk in n.res_blocks]
@@ -157,17 +161,27 @@ class BatchedEvaluator:
         self.vfc1 = (n.value_fc1.weight.detach().to(dt), n.value_fc1.bias.detach().to(dt))
         self.vfc2 = (n.value_fc2.weight.detach().float(), n.value_fc2.bias.detach().float())
 
+    def _conv(self, x, wb, padding, residual=None):
+        """relu(conv(x) + bias (+ residual)) on channels-last tensors."""
+        w, b = wb
+        if not self.fused:
+            y = F.conv2d(x, w, b, padding=padding)
+            return F.relu(y if residual is None else y + residual)
+        from . import engine
+        y = F.conv2d(x, w, None, padding=padding)
+        return engine.bias_act_(y, b, residual, relu=True)
+
     @torch.no_grad()
     def __call__(self, planes):
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
         x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = F.relu(F.conv2d(x, *self.stem, padding=1))
+        x = self._conv(x, self.stem, 1)
         for (c1, c2) in self.blocks:
-            y = F.relu(F.conv2d(x, *c1, padding=1))
-            x = F.relu(F.conv2d(y, *c2, padding=1) + x)
-        p = F.relu(F.conv2d(x, *self.phead)).contiguous().flatten(1)     # NCHW flatten order as the reference
-        v = F.relu(F.conv2d(x, *self.vhead)).contiguous().flatten(1)
+            y = self._conv(x, c1, 1)
+            x = self._conv(y, c2, 1, residual=x)
+        p = self._conv(x, self.phead, 0).contiguous().flatten(1)      # NCHW flatten order as the reference
+        v = self._conv(x, self.vhead, 0).contiguous().flatten(1)
         logits = F.linear(p, *self.pfc).float()
         h = F.relu(F.linear(v, *self.vfc1)).float()
         value = torch.tanh(F.linear(h, *self.vfc2)).reshape(-1)
