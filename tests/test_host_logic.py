@@ -1,0 +1,137 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/yy_engine.h
+declares (no compute without a GPU), the package fails loudly without a device, the network mirror
+(checkpoint format, CPU forward), and the N>1 gather path on gloo with world_size 2."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import yinyang_game_alphazero_amd as pkg
+    so = pkg._lib.build()
+    header = open(os.path.join(ROOT, "include", "yy_engine.h")).read()
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int)\s*\*?\s*(yy_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 24
+    L = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(pkg._lib.exported_symbols())
+    assert L.yy_version() >= 100
+    # argument validation happens before any device work
+    L.yy_last_error.restype = ctypes.c_char_p
+    assert L.yy_rules_valid_mask(None, None, 4, 99, 8, 0, None, None) == -2 and b"16x16" in L.yy_last_error()
+    assert L.yy_rules_valid_mask(None, None, 4, 8, 8, 0, None, None) == -1
+    assert L.yy_mcts_create(None, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.YYError):
+        pkg.engine.BatchedMCTS(2, 8, 8, 10)
+    with pytest.raises(pkg.YYError):
+        pkg.engine.valid_mask(torch.zeros((1, 8, 8), dtype=torch.int8), torch.ones(1, dtype=torch.int8))
+    with pytest.raises(pkg.YYError):
+        pkg.YinYangGame(8, 8).getValidMoves(pkg.YinYangLogic(8, 8), 1)
+
+
+def test_product_never_imports_the_oracle():
+    pkgdir = os.path.join(ROOT, "yinyang-game-alphazero_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in src and "yy_oracle" not in src and "libyy_oracle" not in src, f
+
+
+def test_network_mirror_checkpoint_and_forward(tmp_path):
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(6, 6)
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(game, 16, 2)
+    names = set(net.state_dict())
+    for k in ("conv1.weight", "bn1.running_mean", "res_blocks.1.conv2.bias", "res_blocks.0.bn1.weight",
+              "policy_conv.weight", "policy_bn.bias", "policy_fc.weight", "value_conv.weight", "value_fc1.bias",
+              "value_fc2.weight"):
+        assert k in names                                    # reference layer names (neural_network.py:49-68)
+    path = str(tmp_path / "m" / "best_model.pth.tar")
+    net.save_model(path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"state_dict", "board_size", "action_size"} and tuple(ck["board_size"]) == (6, 6)
+    net2 = pkg.YinYangNeuralNetwork(game, 16, 2)
+    net2.load_model(path)
+    lb = pkg.YinYangLogic(6, 6)
+    lb.board[2, 3], lb.board[0, 0] = 1, -1
+    x = net.board_to_input(lb)                               # CPU module -> host planes
+    import oracle_lib as O
+    assert np.array_equal(x.numpy(), O.encode_planes(lb.board[None])[0])
+    # the two-stone case the reference pins (src/yin_yang/ai/tests.py:82-104)
+    assert x[1, 2, 3] == 1 and x[2, 0, 0] == 1 and x[0, 2, 3] == 0 and x[0, 1, 1] == 1
+    assert abs(float(x[3, 2, 0]) - 1 / 6) < 1e-7 and abs(float(x[4, 0, 3]) - 1 / 6) < 1e-7
+    p1, v1 = net.predict(lb)
+    p2, v2 = net2.predict(lb)
+    assert p1.shape == (36,) and p1.dtype == np.float32 and abs(p1.sum() - 1) < 1e-5 and -1 <= v1 <= 1
+    assert np.array_equal(p1, p2) and v1 == v2
+    with pytest.raises(FileNotFoundError):
+        net.load_model(str(tmp_path / "missing.pth.tar"))
+
+
+def test_children_distribution_known_answers():
+    """mcts_tests.py:159-186, 418-445 restated on the host helper."""
+    from yinyang_game_alphazero_amd.mcts import children_distribution
+    c = np.zeros(9)
+    c[:4] = [10, 5, 3, 1]
+    p = children_distribution(c, 1.0)
+    assert np.allclose(p[:4], np.array([10, 5, 3, 1]) / 19)
+    p0 = children_distribution(c, 0)
+    assert p0[0] == 1.0 and p0[1] == 0.0
+    c2 = np.zeros(9)
+    c2[:3] = [100, 50, 10]
+    d1, d2, d3 = (children_distribution(c2, t) for t in (1.0, 0.5, 0.1))
+    assert d1[0] - d1[1] < d2[0] - d2[1] < d3[0] - d3[1]
+    assert np.allclose(children_distribution(np.zeros(9), 1.0), 1 / 9)
+
+
+GATHER_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from yinyang_game_alphazero_amd.self_play import gather_examples
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+n = 3 + 4 * r                      # ragged shards: 3 and 7 examples
+ex = dict(states=torch.full((n, 4, 4), r, dtype=torch.int8), policies=torch.full((n, 16), float(r)),
+          values=torch.arange(n, dtype=torch.float32) + 100 * r, game_id=torch.arange(n) * w + r,
+          ply=torch.arange(n))
+out = gather_examples(ex)
+assert out["states"].shape == (10, 4, 4), out["states"].shape
+assert out["values"].tolist() == [0, 1, 2] + [100 + i for i in range(7)]
+assert out["states"][:3].eq(0).all() and out["states"][3:].eq(1).all()
+assert out["game_id"].tolist() == [0, 2, 4] + [1 + 2 * i for i in range(7)]
+empty = {k: v[:0] for k, v in ex.items()}
+out2 = gather_examples(empty if r == 0 else ex)         # an empty shard contributes nothing
+assert out2["states"].shape[0] == 7
+dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+
+
+def test_gather_examples_gloo_world2(tmp_path):
+    script = tmp_path / "gather.py"
+    script.write_text(GATHER_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", str(script), ROOT],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok") == 2
