@@ -45,8 +45,6 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--kernel-timing-steps", type=int, default=64,
-                    help="lockstep steps timed with HIP events for the roofline object")
     return ap.parse_args()
 
 
@@ -86,50 +84,70 @@ def stagger_start(eng, seed):
     eng.games_target = 1 << 60          # refill forever
 
 
-def hip_event_kernel_time(eng, n_steps):
-    """Average duration of the fused tree kernel (yy_mcts_step) measured with HIP events recorded on
-    the stream the kernel is launched on, through the HIP runtime directly (not torch.cuda.Event)."""
-    hip = ctypes.CDLL("libamdhip64.so")
-    ev_t = ctypes.c_void_p
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ctx, evaluator = eng.ctx, eng.evaluator
-    starts, stops = [], []
-    for _ in range(n_steps):
-        a, b = ev_t(), ev_t()
-        assert hip.hipEventCreate(ctypes.byref(a)) == 0 and hip.hipEventCreate(ctypes.byref(b)) == 0
-        starts.append(a)
-        stops.append(b)
-    # a fresh search so that a select is pending
-    rp = eng.players.contiguous()
-    ctx.begin(eng.boards, rp, None)
-    policy, _ = evaluator(ctx.planes)
-    ctx.expand_root(policy, None, 0.25)
-    ctx.select()
-    ctx.reset_counters()
-    nn_ms = []
-    for i in range(n_steps):
-        t0 = torch.cuda.Event(enable_timing=True)
-        t1 = torch.cuda.Event(enable_timing=True)
-        t0.record()
-        policy, value = evaluator(ctx.planes)
-        t1.record()
-        nn_ms.append((t0, t1))
-        assert hip.hipEventRecord(starts[i], stream) == 0
-        ctx.step(policy, value)
-        assert hip.hipEventRecord(stops[i], stream) == 0
+class HipEventTimer:
+    """HIP events (hipEventRecord on the stream the kernel is launched on, via the HIP runtime itself,
+    not torch.cuda.Event) around every launch of the fused tree kernel."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.pairs = []
+        for _ in range(n):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+        self.i = 0
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def start(self):
+        if self.i < len(self.pairs):
+            assert self.hip.hipEventRecord(self.pairs[self.i][0], self._stream()) == 0
+
+    def stop(self):
+        if self.i < len(self.pairs):
+            assert self.hip.hipEventRecord(self.pairs[self.i][1], self._stream()) == 0
+            self.i += 1
+
+    def mean_ms(self):
+        torch.cuda.synchronize()
+        ms, tot = ctypes.c_float(0), 0.0
+        for a, b in self.pairs[: self.i]:
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            tot += ms.value
+        for a, b in self.pairs:
+            self.hip.hipEventDestroy(a)
+            self.hip.hipEventDestroy(b)
+        return tot / max(self.i, 1), self.i
+
+
+def roofline_pass(eng):
+    """One more move of the SAME workload, launched eagerly (same kernels as the graph replays) with HIP
+    events around every fused tree-kernel launch; returns (mean kernel ms, launches, device counters of
+    exactly those launches, mean evaluator-forward ms)."""
+    eng.search.use_graph, eng.search.graph = False, None
+    eng.ctx.reset_counters()
+    timer = HipEventTimer(eng.sims)
+    eng.search.timer = timer
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    eng.play_move()
+    t1.record()
+    eng.search.timer = None
+    k_ms, n = timer.mean_ms()
+    counters = eng.ctx.status()
+    move_ms = t0.elapsed_time(t1)
+    # evaluator forward alone, same batch
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        eng.evaluator(eng.ctx.planes)
+    e1.record()
     torch.cuda.synchronize()
-    ms = ctypes.c_float(0)
-    tot = 0.0
-    for a, b in zip(starts, stops):
-        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
-        tot += ms.value
-        hip.hipEventDestroy(a)
-        hip.hipEventDestroy(b)
-    counters = ctx.status()
-    policy, value = evaluator(ctx.planes)
-    ctx.expand_backup(policy, value)
-    nn = sum(a.elapsed_time(b) for a, b in nn_ms) / n_steps
-    return tot / n_steps, nn, counters
+    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms
 
 
 def algorithmic_bytes(counters, G, A, n_steps, nw):
@@ -244,19 +262,20 @@ def main():
     roof = cpub = None
     extra = {}
     if rank == 0:
-        k_ms, nn_ms, kc = hip_event_kernel_time(eng, args.kernel_timing_steps)
+        k_ms, n_launch, kc, nn_ms, eager_move_ms = roofline_pass(eng)
         nw = (args.rows * args.cols + 63) // 64
-        bytes_per_launch, shape = algorithmic_bytes(kc, args.games, args.rows * args.cols, args.kernel_timing_steps, nw)
+        bytes_per_launch, shape = algorithmic_bytes(kc, args.games, args.rows * args.cols, n_launch, nw)
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": bytes_per_launch, **shape}
+                "avg_launch_ms": k_ms, "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "pmc_profile": "profiles/ (rocprofv3 --pmc passes are collected offline; see DESIGN.md)", **shape}
         A = args.rows * args.cols
         Cc = args.channels
         flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
                       + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
         extra = {"nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
-                 "tree_kernel_ms": k_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
+                 "tree_kernel_ms": k_ms, "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
         if not args.no_cpu_baseline:
             cpub = cpu_baseline(args)
     if dist is not None:

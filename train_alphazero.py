@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Same-flag entry point as the reference's train_alphazero.py (train_alphazero.py:30-61), running
+`--mode self-play` on the MI355X engine.
+
+    python train_alphazero.py --mode self-play --rows 8 --cols 8 --simulations 800 --episodes 4096
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_alphazero.py --mode self-play ...
+
+Flags added to the reference's set: --concurrent-games, --board-semantics {copied,aliased},
+--reference-quirks, --nn {bf16,fp32}, --seed.  `--mode train` / `--mode evaluate` (orchestration,
+trainer, arena: SURVEY.md 8f-2/3) are outside the hot path this repository covers.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Yin-Yang AlphaZero self-play on MI355X")
+    p.add_argument("--rows", type=int, default=8)
+    p.add_argument("--cols", type=int, default=8)
+    p.add_argument("--iterations", type=int, default=100)
+    p.add_argument("--episodes", type=int, default=100)
+    p.add_argument("--simulations", type=int, default=800)
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--batch-size", type=int, default=64)
+    p.add_argument("--lr", type=float, default=0.001)
+    p.add_argument("--workers", type=int, default=1)
+    p.add_argument("--mcts-threads", type=int, default=1)
+    p.add_argument("--model-dir", type=str, default="models")
+    p.add_argument("--data-dir", type=str, default="data")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--mode", choices=["train", "self-play", "evaluate"], default="train")
+    p.add_argument("--output-model", type=str, default="best_model.pth.tar")
+    # engine flags
+    p.add_argument("--concurrent-games", type=int, default=4096)
+    p.add_argument("--board-semantics", choices=["copied", "aliased"], default="copied")
+    p.add_argument("--reference-quirks", action="store_true", help="reproduce Q4/Q5 of the reference's play_game")
+    p.add_argument("--nn", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--seed", type=int, default=0)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("train_alphazero.py: no ROCm device -- the self-play engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(args.rows, args.cols)
+    for d in (args.model_dir, args.data_dir):
+        os.makedirs(d, exist_ok=True)
+    if args.mode != "self-play":
+        sys.exit(f"--mode {args.mode}: orchestration/trainer/arena are outside this repository's hot-path scope "
+                 "(SURVEY.md 8f); use --mode self-play")
+    model_path = os.path.join(args.model_dir, args.output_model)
+    if not os.path.exists(model_path):           # same contract as the reference (train_alphazero.py:107-109)
+        sys.exit(f"Model file not found: {model_path}")
+    path = pkg.generate_self_play_data(game, model_path, args.data_dir, num_games=args.episodes,
+                                       num_workers=args.workers, num_simulations=args.simulations,
+                                       concurrent_games=args.concurrent_games, board_semantics=args.board_semantics,
+                                       reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed)
+    if rank == 0:
+        st = pkg.generate_self_play_data.last_stats
+        st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])
+        print(json.dumps({"data_file": path, "rank0_stats": st}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,10 +40,15 @@ class LockstepSearch:
         self.ctx, self.evaluator, self.use_graph = ctx, evaluator, use_graph
         self.eager_sims = eager_sims
         self.graph = None
+        self.timer = None      # optional object with start()/stop() bracketing every tree-kernel launch (bench.py)
 
     def _sim_step(self):
         policy, value = self.evaluator(self.ctx.planes)
+        if self.timer is not None:
+            self.timer.start()
         self.ctx.step(policy, value)
+        if self.timer is not None:
+            self.timer.stop()
 
     def run(self, boards, root_players, num_sims, noise=None, eps=0.25, active=None):
         ctx = self.ctx
