@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA ~2.5 PFLOP/s dense
 
 
 def parse():
@@ -147,7 +148,18 @@ def roofline_pass(eng):
         eng.evaluator(eng.ctx.planes)
     e1.record()
     torch.cuda.synchronize()
-    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms
+    # the tower kernel alone (HIP events on its launch stream), when the evaluator uses it
+    tower_ms = None
+    ev = eng.evaluator
+    if getattr(ev, "tower", False):
+        from yinyang_game_alphazero_amd import engine as E
+        tt = HipEventTimer(reps)
+        for _ in range(reps):
+            tt.start()
+            E.tower_forward(eng.ctx.planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+            tt.stop()
+        tower_ms, _ = tt.mean_ms()
+    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms
 
 
 def algorithmic_bytes(counters, G, A, n_steps, nw):
@@ -210,7 +222,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torchrun the RCCL path is exercised even at N=1
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import yinyang_game_alphazero_amd as pkg
@@ -262,19 +274,33 @@ def main():
     roof = cpub = None
     extra = {}
     if rank == 0:
-        k_ms, n_launch, kc, nn_ms, eager_move_ms = roofline_pass(eng)
+        k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms = roofline_pass(eng)
         nw = (args.rows * args.cols + 63) // 64
         bytes_per_launch, shape = algorithmic_bytes(kc, args.games, args.rows * args.cols, n_launch, nw)
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k_mcts_pmc.json")
+        if os.path.exists(pmc) and (args.games, args.rows, args.cols, args.sims) == (4096, 8, 8, 800):
+            traffic = json.load(open(pmc))["per_launch_bytes"]["traffic_corrected"]
+        roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": k_ms, "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "pmc_profile": "profiles/ (rocprofv3 --pmc passes are collected offline; see DESIGN.md)", **shape}
+        roof = roof_tree
+        if tower_ms is not None:
+            # dominant kernel of a step = the LDS-resident MFMA tower (csrc/yy_tower.hip): algorithmic FLOPs per
+            # board = stem with K padded to 16 + 2 convs per block, each 2*9*128*128*64
+            tower_flops = (2 * 9 * 16 * 128 * 64 + 2 * args.blocks * (2 * 9 * 128 * 128 * 64)) * args.games
+            ach = tower_flops / (tower_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_tower (stem + residual tower, bf16 MFMA, activations LDS-resident)",
+                    "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
+            extra["roofline_tree_kernel"] = roof_tree
         A = args.rows * args.cols
         Cc = args.channels
         flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
                       + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
-        extra = {"nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
+        extra = {**extra, "nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
                  "tree_kernel_ms": k_ms, "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
         if not args.no_cpu_baseline:
             cpub = cpu_baseline(args)

@@ -172,6 +172,15 @@ int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);
 int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_t rows, int C,
                         int relu, yy_stream_t stream);
 
+/* The residual tower of the evaluator (stem + residual blocks, ai/neural_network.py:16-33, 105-110)
+ * as ONE LDS-resident MFMA kernel: planes float32 [G,5,8,8] -> out bf16 [G,8,8,128] (channels-last
+ * activations after the last block).  weights: bf16 chunks in fragment order and bias float32
+ * [n_layers,128], both produced on the host from the module with eval-mode BatchNorm folded
+ * (network.pack_tower).  n_layers = 1 + 2*res_blocks.  8x8 boards and 128 channels only
+ * (YY_E_UNSUPPORTED otherwise). */
+int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G,
+                     int R, int C, int channels, int n_layers, yy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,3 +57,49 @@ def test_fp32_module_matches_cpu_module():
     pc, vc = net.predict_batch(planes)
     pg, vg = net.cuda().predict_batch(planes.cuda())
     assert float((pg.cpu() - pc).abs().max()) < 1e-4 and float((vg.cpu() - vc).abs().max()) < 1e-4
+
+
+def test_tower_kernel_matches_torch_bf16_path():
+    """LDS-resident MFMA tower (csrc/yy_tower.hip) vs the same folded bf16 weights run through torch
+    convolutions + the fused epilogue.  Both round activations to bf16 after every layer and accumulate
+    in f32; they differ only in summation order, so: activations within 2 bf16 ulps relative (2^-7) of
+    the layer-output scale, final policy within 2e-2 abs, value within 5e-2 abs (the same bounds as bf16 vs fp32:
+    two bf16 evaluations of a 21-layer net differ by rounding noise of that size)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(8, 8)
+    rng = np.random.default_rng(3)
+    for blocks, G in ((1, 7), (3, 64), (10, 130)):
+        net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+        # non-trivial BatchNorm statistics and biases so that folding and the bias path are exercised
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.1)
+                if isinstance(m, torch.nn.Conv2d):
+                    m.bias.normal_(0, 0.05)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        ref = pkg.BatchedEvaluator(net, "bf16", tower=False)
+        tow = pkg.BatchedEvaluator(net, "bf16", tower=True)
+        assert tow.tower and not ref.tower
+        # tower activations
+        x_t = pkg.engine.tower_forward(planes, tow.tower_w, tow.tower_b, tow.tower_layers).float()
+        x = planes.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x = ref._conv(x, ref.stem, 1)
+        for (c1, c2) in ref.blocks:
+            y = ref._conv(x, c1, 1)
+            x = ref._conv(y, c2, 1, residual=x)
+        x_r = x.float()
+        scale = float(x_r.abs().max())
+        err = float((x_t - x_r).abs().max())
+        assert err <= scale * 2.0 ** -7 * (1 + blocks), (blocks, err, scale)
+        p_t, v_t = tow(planes)
+        p_r, v_r = ref(planes)
+        assert float((p_t - p_r).abs().max()) < 2e-2 and float((v_t - v_r).abs().max()) < 5e-2
+        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+        assert float((p_t - p32).abs().max()) < 2e-2 and float((v_t - v32).abs().max()) < 5e-2

@@ -32,11 +32,12 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_bitboard.h"), HEADER]
+    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"),
+            os.path.join(CSRC, "yy_bitboard.h"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, srcs[0]]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, srcs[0], srcs[1]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -69,6 +70,7 @@ _SIGS = {
     "yy_mcts_status": [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)],
     "yy_mcts_reset_counters": [_vp, _vp],
     "yy_nn_bias_act_bf16": [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp],
+    "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_version": [],
 }
 

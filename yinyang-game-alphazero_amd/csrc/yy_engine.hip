@@ -42,6 +42,7 @@ static int set_err(int code, const char *fmt, const char *a = "", const char *b 
     } while (0)
 
 extern "C" const char *yy_last_error(void) { return g_err; }
+extern "C" int yy_tower_set_err(int code, const char *msg) { return set_err(code, "%s%s", msg); }   // for yy_tower.hip
 extern "C" int yy_version(void) { return YY_VERSION; }
 
 static int check_geo(int G, int R, int C) {

@@ -1,0 +1,236 @@
+// yy_tower.hip -- the policy/value CNN's residual tower as ONE LDS-resident MFMA kernel (gfx950).
+//
+// Reference computation: YinYangNeuralNetwork.forward, stem + residual blocks
+// (src/yin_yang/ai/neural_network.py:16-33, 94-110) at eval time with BatchNorm folded into the
+// convolutions, on 8x8 boards with 128 channels, bf16 storage / f32 accumulation.
+//
+// MI355X design.  A 3x3 convolution on an 8x8 board never looks outside its board, so the whole
+// tower of a board can run inside one workgroup with no inter-workgroup dependency:
+//   * workgroup = 4 waves = 4 boards (wave w owns board w: its 64 cells are the MFMA columns);
+//   * the boards' activations [64 cells][128 ch] bf16 live in LDS for ALL layers (64 KB, XOR-swizzled
+//     16-B slots so ds_read_b128 fragment reads are conflict-free); they never touch HBM;
+//   * each layer is an implicit GEMM  D[cout][cell] = sum_{tap,cin} W[cout][tap,cin] * X[cin][cell+tap]
+//     on v_mfma_f32_32x32x16_bf16 (weights = A operand, shifted activations = B operand; out-of-board
+//     taps read a zero row); a wave accumulates its full 128 x 64 output tile in 128 accumulator
+//     registers, then applies bias (pre-loaded into the accumulators), residual (kept packed in
+//     registers) and ReLU and writes bf16 back to LDS;
+//   * weights stream L2 -> LDS with global_load_lds_dwordx4 through a 5-slot ring of 16 KB chunks
+//     (one chunk = one tap x 64 input channels, pre-packed on the host in fragment order), counted
+//     s_waitcnt vmcnt + raw s_barrier, 4 chunks (~2 taps of compute) in flight;
+//   * LDS: 64 KB activations + 80 KB ring + 12.25 KB bias table + zero row = 160 KB -> 1 workgroup/CU,
+//     one wave per SIMD with the whole register file.
+// Roofline: MFMA (bf16 dense 2.5 PFLOP/s).  Algorithmic FLOPs per board: 2*9*16*128*64 (stem, K padded
+// to 16) + (layers-1) * 2*9*128*128*64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yy_engine.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define TW_TB 4
+#define TW_CH 128
+#define TW_CELLS 64
+#define TW_ACT_BYTES (TW_TB * TW_CELLS * TW_CH * 2)        // 65536
+#define TW_CHUNK_BYTES 16384                               // [ks 4][ntile 4][h 2][c 32][j 8] bf16
+#define TW_NSLOT 5
+#define TW_RING_OFF TW_ACT_BYTES
+#define TW_BIAS_OFF (TW_RING_OFF + TW_NSLOT * TW_CHUNK_BYTES)   // 147456
+#define TW_MAX_LAYERS 24
+#define TW_ZERO_OFF (TW_BIAS_OFF + TW_MAX_LAYERS * TW_CH * 4)   // 159744, 256 B of zeros
+#define TW_LDS_BYTES 163840
+
+extern "C" int yy_tower_set_err(int code, const char *msg);   // defined in yy_engine.hip
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    bf16x2 t;
+    t[0] = (__bf16)a;
+    t[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+
+// byte offset of the 16-B slot holding channels [8*chunk, 8*chunk+8) of (board, cell)
+__device__ __forceinline__ uint32_t act_off(int board, int cell, int chunk) {
+    return (uint32_t)(((board * TW_CELLS + cell) * 16 + (chunk ^ (cell & 15))) * 16);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// every thread moves 4 x 16 B of a 16 KB chunk: global (fragment order) -> LDS ring slot, no VGPR data
+__device__ __forceinline__ void issue_chunk(const unsigned char *wchunk, unsigned char *lds, int slot, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int piece = (r * 4 + wave) * 1024;   // wave-uniform 1 KiB piece
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wchunk + piece + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds + TW_RING_OFF + slot * TW_CHUNK_BYTES + piece),
+                                         16, 0, 0);
+    }
+}
+
+// One chunk = one tap x (KS k-steps of 16 input channels): 8*KS MFMAs per wave.
+template <int KS>
+__device__ __forceinline__ void compute_chunk(f32x16 (&acc)[2][4], const unsigned char *lds, int slot, int half,
+                                              const uint32_t (&cbase)[2], const uint32_t (&csw)[2], int lane) {
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned char *wslot = lds + TW_RING_OFF + slot * TW_CHUNK_BYTES + (h * 32 + c) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int cc = half * 8 + ks * 2 + h;   // 16-B channel slot this lane's fragment covers
+        bf16x8 xf[2], wf[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+            xf[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + cbase[tt] + (((uint32_t)cc ^ csw[tt]) << 4)));
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+            wf[nt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wslot + (ks * 4 + nt) * 1024));
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+                acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[tt], acc[tt][nt], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
+        unsigned short *__restrict__ out, int G, int n_layers) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TW_LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gb = blockIdx.x * TW_TB + wave;              // this wave's board
+    const int h = lane >> 5, c = lane & 31;
+
+    // ---- prologue: bias table + zero row + input planes -> LDS (ordinary loads, drained before the ring starts)
+    for (int i = threadIdx.x; i < n_layers * TW_CH; i += 256) ((float *)(lds + TW_BIAS_OFF))[i] = bias[i];
+    if (threadIdx.x < 64) ((uint32_t *)(lds + TW_ZERO_OFF))[threadIdx.x] = 0u;
+    {
+        // lane = cell: 5 planes (neural_network.py:156-196) -> channels 0..4 of a 16-channel input, rest zero
+        float p[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) p[k] = (gb < G) ? planes[((size_t)gb * 5 + k) * TW_CELLS + lane] : 0.0f;
+        u32x4 v0 = {pack_bf16(p[0], p[1]), pack_bf16(p[2], p[3]), pack_bf16(p[4], 0.0f), 0u};
+        u32x4 z = {0u, 0u, 0u, 0u};
+        *(u32x4 *)(lds + act_off(wave, lane, 0)) = v0;
+        *(u32x4 *)(lds + act_off(wave, lane, 1)) = z;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    const int n_chunks = 9 + 18 * (n_layers - 1);
+#pragma unroll
+    for (int pc = 0; pc < 4; pc++)
+        if (pc < n_chunks) issue_chunk(weights + (size_t)pc * TW_CHUNK_BYTES, lds, pc % TW_NSLOT, wave, lane);
+
+    // this lane's two cells (MFMA columns): tile 0 = board rows 0-3, tile 1 = rows 4-7
+    const int cy[2] = {c >> 3, 4 + (c >> 3)}, cx = c & 7;
+    uint32_t res[2][4][4][2];   // residual x, packed bf16 in the accumulator layout
+    int chunk = 0;
+
+    for (int L = 0; L < n_layers; L++) {
+        f32x16 acc[2][4];
+        // accumulators start at the bias: lane's rows of tile nt are couts nt*32 + 8q + 4h + i
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b = *(const f32x4 *)(lds + TW_BIAS_OFF + (L * TW_CH + nt * 32 + 8 * q + 4 * h) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    acc[0][nt][4 * q + i] = b[i];
+                    acc[1][nt][4 * q + i] = b[i];
+                }
+            }
+        const int halves = (L == 0) ? 1 : 2;
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            uint32_t cbase[2], csw[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                const int sy = cy[tt] + dy, sx = cx + dx;
+                const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
+                const int sc = sy * 8 + sx;
+                cbase[tt] = ok ? (uint32_t)((wave * TW_CELLS + sc) * 256) : (uint32_t)TW_ZERO_OFF;
+                csw[tt] = ok ? (uint32_t)(sc & 15) : 0u;
+            }
+            for (int half = 0; half < halves; half++, chunk++) {
+                // my pieces of `chunk` have landed when at most the newer chunks' loads are outstanding
+                const int newer = min(3, n_chunks - 1 - chunk);
+                if (newer == 3) wait_vmcnt<12>();
+                else if (newer == 2) wait_vmcnt<8>();
+                else if (newer == 1) wait_vmcnt<4>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone finished chunk-1
+                asm volatile("" ::: "memory");
+                if (chunk + 4 < n_chunks)
+                    issue_chunk(weights + (size_t)(chunk + 4) * TW_CHUNK_BYTES, lds, (chunk + 4) % TW_NSLOT, wave, lane);
+                if (L == 0) compute_chunk<1>(acc, lds, chunk % TW_NSLOT, 0, cbase, csw, lane);
+                else compute_chunk<4>(acc, lds, chunk % TW_NSLOT, half, cbase, csw, lane);
+            }
+        }
+        // ---- epilogue (wave-private: a wave reads and writes only its own board's cells)
+        const bool conv2 = (L >= 2) && ((L & 1) == 0);   // second conv of a block: + residual
+        const bool keep = (L == 0) || conv2;             // output is a block input x: keep it for the skip
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+            const int cell = tt * 32 + c;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float v0 = acc[tt][nt][4 * q + 0], v1 = acc[tt][nt][4 * q + 1];
+                    float v2 = acc[tt][nt][4 * q + 2], v3 = acc[tt][nt][4 * q + 3];
+                    if (conv2) {
+                        v0 += bf_lo(res[tt][nt][q][0]);
+                        v1 += bf_hi(res[tt][nt][q][0]);
+                        v2 += bf_lo(res[tt][nt][q][1]);
+                        v3 += bf_hi(res[tt][nt][q][1]);
+                    }
+                    const uint32_t p0 = pack_bf16(fmaxf(v0, 0.0f), fmaxf(v1, 0.0f));
+                    const uint32_t p1 = pack_bf16(fmaxf(v2, 0.0f), fmaxf(v3, 0.0f));
+                    if (keep) {
+                        res[tt][nt][q][0] = p0;
+                        res[tt][nt][q][1] = p1;
+                    }
+                    u32x2 pk = {p0, p1};
+                    *(u32x2 *)(lds + act_off(wave, cell, nt * 4 + q) + h * 8) = pk;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- final activations -> HBM, [board][cell][128] bf16 (channels-last), un-swizzled, 1 KiB per wave store
+    __syncthreads();
+    if (gb < G) {
+        const int ch = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int cell = (lane >> 4) + 4 * i;
+            const u32x4 v = *(const u32x4 *)(lds + act_off(wave, cell, ch));
+            *(u32x4 *)(out + ((size_t)gb * TW_CELLS + cell) * TW_CH + ch * 8) = v;
+        }
+    }
+}
+
+// weights: bf16 chunks [9 + 18*(n_layers-1)][8192] in fragment order (network.pack_tower);
+// bias f32 [n_layers][128]; planes f32 [G,5,8,8]; out bf16 [G,8,8,128].
+extern "C" int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G, int R,
+                                int C, int channels, int n_layers, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (!planes || !weights || !bias || !out || G < 0) return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_bf16: bad argument");
+    if (R != 8 || C != 8 || channels != TW_CH || n_layers < 1 || n_layers > TW_MAX_LAYERS || (n_layers & 1) == 0)
+        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_bf16: needs 8x8 boards, 128 channels, 1 + 2*blocks <= 23 layers");
+    k_tower<<<dim3((G + TW_TB - 1) / TW_TB), dim3(256), 0, (hipStream_t)s>>>(planes, (const unsigned char *)weights, bias,
+                                                                           (unsigned short *)out, G, n_layers);
+    if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_bf16: launch failed");
+    return YY_OK;
+}

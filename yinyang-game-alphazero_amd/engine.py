@@ -136,6 +136,20 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
+def tower_forward(planes, weights, bias, n_layers):
+    """Stem + residual tower in one LDS-resident MFMA kernel (csrc/yy_tower.hip).
+    planes f32 [G,5,8,8] -> bf16 activations as a channels-last tensor [G,128,8,8]."""
+    G = planes.shape[0]
+    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    n_chunks = 9 + 18 * (n_layers - 1)
+    _need(weights, torch.int16, (n_chunks, 8192), "tower weights")
+    _need(bias, torch.float32, (n_layers, 128), "tower bias")
+    out = torch.empty((G, 8, 8, 128), dtype=torch.bfloat16, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_bf16(_p(planes), _p(weights), _p(bias), _p(out), G, 8, 8, 128, n_layers, _stream()))
+    return out.permute(0, 3, 1, 2)      # NCHW view of NHWC memory == channels_last
+
+
 # ------------------------------------------------------------------ batched MCTS context
 class BatchedMCTS:
     """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate

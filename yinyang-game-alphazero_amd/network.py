@@ -125,6 +125,35 @@ def fold_batchnorm(conv, bn):
     return w.detach(), b.detach()
 
 
+def pack_tower(net):
+    """Fold eval-mode BatchNorm and pack the stem + residual-block convolutions of `net` (8x8 boards,
+    128 channels) into the fragment order csrc/yy_tower.hip streams:
+    weights int16(bf16 bits) [n_chunks, 8192] with chunk = [ks 4][ntile 4][h 2][c 32][j 8],
+    cout = ntile*32 + c, cin = half*64 + ks*16 + h*8 + j; layer 0 (stem) has 9 chunks (one per tap,
+    5 input planes zero-padded to 16 channels), every other layer 18 (tap-major, then half);
+    bias float32 [n_layers, 128]."""
+    convs = [(net.conv1, net.bn1)]
+    for blk in net.res_blocks:
+        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    chunks, biases = [], []
+    for li, (conv, bn) in enumerate(convs):
+        w, b = fold_batchnorm(conv, bn)                       # [128, cin, 3, 3], [128]
+        w = w.float().cpu()
+        cout, cin = w.shape[0], w.shape[1]
+        assert cout == 128 and w.shape[2:] == (3, 3) and (cin == 128 or li == 0)
+        wp = torch.zeros((128, 128, 3, 3))
+        wp[:, :cin] = w
+        for tap in range(9):
+            wt = wp[:, :, tap // 3, tap % 3]                  # [cout, cin]
+            t = wt.reshape(4, 32, 2, 4, 2, 8)                 # nt, c, half, ks, h, j
+            t = t.permute(2, 3, 0, 4, 1, 5).contiguous()      # half, ks, nt, h, c, j
+            for half in range(1 if li == 0 else 2):
+                chunks.append(t[half].reshape(-1))
+        biases.append(b.float().cpu())
+    wq = torch.stack(chunks).to(torch.bfloat16).view(torch.int16).contiguous()
+    return wq, torch.stack(biases).contiguous()
+
+
 class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
@@ -136,14 +165,22 @@ class BatchedEvaluator:
     the 3-4 elementwise kernels PyTorch would launch.
     """
 
-    def __init__(self, net, mode="fp32", fused_epilogue=True):
+    def __init__(self, net, mode="fp32", fused_epilogue=True, tower=True):
         self.net = net.eval()
         self.mode = mode
         self.device = next(net.parameters()).device
         self.fused = bool(fused_epilogue) and mode == "bf16"
+        # the LDS-resident MFMA tower kernel (csrc/yy_tower.hip) covers the stem + residual blocks for
+        # 8x8 boards with 128 channels; other shapes use MIOpen convolutions + the fused epilogue
+        self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) == (8, 8)
+                      and net.conv1.out_channels == 128 and 1 + 2 * len(net.res_blocks) <= 23)
         if mode != "fp32":
             self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
             self._fold()
+        if self.tower:
+            wq, bq = pack_tower(net)
+            self.tower_w, self.tower_b = wq.to(self.device), bq.to(self.device)
+            self.tower_layers = 1 + 2 * len(net.res_blocks)
 
     def _fold(self):
         n, dt = self.net, self.dtype
@@ -175,11 +212,15 @@ class BatchedEvaluator:
     def __call__(self, planes):
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
-        x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = self._conv(x, self.stem, 1)
-        for (c1, c2) in self.blocks:
-            y = self._conv(x, c1, 1)
-            x = self._conv(y, c2, 1, residual=x)
+        if self.tower:
+            from . import engine
+            x = engine.tower_forward(planes, self.tower_w, self.tower_b, self.tower_layers)
+        else:
+            x = planes.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            x = self._conv(x, self.stem, 1)
+            for (c1, c2) in self.blocks:
+                y = self._conv(x, c1, 1)
+                x = self._conv(y, c2, 1, residual=x)
         p = self._conv(x, self.phead, 0).contiguous().flatten(1)      # NCHW flatten order as the reference
         v = self._conv(x, self.vhead, 0).contiguous().flatten(1)
         logits = F.linear(p, *self.pfc).float()

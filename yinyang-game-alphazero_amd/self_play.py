@@ -268,7 +268,7 @@ def gather_examples(ex, group=None):
     the return_queue.get loop (self_play.py:311-315).  Every rank returns the concatenation in rank
     order."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return ex
     world = dist.get_world_size(group)
     dev = ex["states"].device
