@@ -79,27 +79,97 @@ __device__ __forceinline__ void issue_chunk(const unsigned char *wchunk, unsigne
     }
 }
 
-// One chunk = one tap x (KS k-steps of 16 input channels): 8*KS MFMAs per wave.
-template <int KS>
-__device__ __forceinline__ void compute_chunk(f32x16 (&acc)[2][4], const unsigned char *lds, int slot, int half,
-                                              const uint32_t (&cbase)[2], const uint32_t (&csw)[2], int lane) {
+// fragments of one k-step (16 input channels of one tap): 2 activation tiles + 4 weight tiles, 6 ds_read_b128
+struct Frags {
+    bf16x8 x[2], w[4];
+};
+__device__ __forceinline__ void load_frags(Frags &f, const unsigned char *lds, int slot, int half, int ks,
+                                           const uint32_t (&cbase)[2], const uint32_t (&csw)[2], int lane) {
     const int h = lane >> 5, c = lane & 31;
-    const unsigned char *wslot = lds + TW_RING_OFF + slot * TW_CHUNK_BYTES + (h * 32 + c) * 16;
+    const int cc = half * 8 + ks * 2 + h;   // 16-B channel slot this lane's fragment covers
+    const unsigned char *wslot = lds + TW_RING_OFF + slot * TW_CHUNK_BYTES + (h * 32 + c) * 16 + ks * 4096;
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int cc = half * 8 + ks * 2 + h;   // 16-B channel slot this lane's fragment covers
-        bf16x8 xf[2], wf[4];
+    for (int tt = 0; tt < 2; tt++)
+        f.x[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + cbase[tt] + (((uint32_t)cc ^ csw[tt]) << 4)));
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++)
-            xf[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + cbase[tt] + (((uint32_t)cc ^ csw[tt]) << 4)));
+    for (int nt = 0; nt < 4; nt++) f.w[nt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wslot + nt * 1024));
+}
+__device__ __forceinline__ void mma8(f32x16 (&acc)[2][4], const Frags &f) {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
-            wf[nt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wslot + (ks * 4 + nt) * 1024));
+            acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nt], f.x[tt], acc[tt][nt], 0, 0, 0);
+}
+// issue order hint: the 6 LDS reads of the NEXT k-step interleaved with the 8 MFMAs of the current one
+__device__ __forceinline__ void interleave_hint() {
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++)
+    for (int j = 0; j < 3; j++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);       // 5 MFMAs cover the last reads' latency
+}
+// cell geometry of a tap for this lane's two cells: LDS row base and swizzle key (zero row when off-board)
+__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int wave, uint32_t (&cbase)[2], uint32_t (&csw)[2]) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-                acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[tt], acc[tt][nt], 0, 0, 0);
+    for (int tt = 0; tt < 2; tt++) {
+        const int sy = cy[tt] + dy, sx = cx + dx;
+        const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
+        const int sc = sy * 8 + sx;
+        cbase[tt] = ok ? (uint32_t)((wave * TW_CELLS + sc) * 256) : (uint32_t)TW_ZERO_OFF;
+        csw[tt] = ok ? (uint32_t)(sc & 15) : 0u;
+    }
+}
+
+// One layer's chunks.  Invariant on entry and exit of every iteration: chunk `chunk` is visible in its
+// ring slot to every wave.  Each iteration first makes chunk+1 visible (counted vmcnt + barrier), refills
+// the slot chunk-1 used, then runs KS k-steps whose LDS reads are software-pipelined one k-step ahead,
+// across the chunk boundary too (only the first k-step of a layer exposes its read latency).
+template <int KS>
+__device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *lds, const unsigned char *weights, int &chunk,
+                                          int n_chunks, const int (&cy)[2], int cx, int wave, int lane) {
+    constexpr int NCH = (KS == 1) ? 9 : 18;
+    uint32_t cb[2], cs[2];
+    tap_geo(0, cy, cx, wave, cb, cs);
+    Frags cur;
+    load_frags(cur, lds, chunk % TW_NSLOT, 0, 0, cb, cs, lane);
+    for (int i = 0; i < NCH; i++, chunk++) {
+        const int half = (KS == 1) ? 0 : (i & 1);
+        if (chunk + 1 < n_chunks) {
+            const int newer = min(2, n_chunks - 2 - chunk);   // chunks younger than chunk+1 still in flight
+            if (newer == 2) wait_vmcnt<8>();
+            else if (newer == 1) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // chunk+1 landed everywhere; everyone finished chunk-1
+            asm volatile("" ::: "memory");
+            if (chunk + 4 < n_chunks)
+                issue_chunk(weights + (size_t)(chunk + 4) * TW_CHUNK_BYTES, lds, (chunk + 4) % TW_NSLOT, wave, lane);
+        }
+        const bool last = (i == NCH - 1);
+        uint32_t ncb[2], ncs[2];
+        const int ni = last ? i : i + 1;
+        tap_geo((KS == 1) ? ni : (ni >> 1), cy, cx, wave, ncb, ncs);
+        const int nhalf = (KS == 1) ? 0 : (ni & 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            Frags nxt;
+            if (ks + 1 < KS) {
+                load_frags(nxt, lds, chunk % TW_NSLOT, half, ks + 1, cb, cs, lane);
+                mma8(acc, cur);
+                interleave_hint();
+                cur = nxt;
+            } else if (!last) {
+                load_frags(nxt, lds, (chunk + 1) % TW_NSLOT, nhalf, 0, ncb, ncs, lane);
+                mma8(acc, cur);
+                interleave_hint();
+                cur = nxt;
+            } else {
+                mma8(acc, cur);
+            }
+        }
+        cb[0] = ncb[0]; cb[1] = ncb[1]; cs[0] = ncs[0]; cs[1] = ncs[1];
     }
 }
 
@@ -132,6 +202,12 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
     for (int pc = 0; pc < 4; pc++)
         if (pc < n_chunks) issue_chunk(weights + (size_t)pc * TW_CHUNK_BYTES, lds, pc % TW_NSLOT, wave, lane);
 
+    // chunk 0 visible to everyone before the first layer (3 younger chunks may stay in flight)
+    if (n_chunks >= 4) wait_vmcnt<12>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
     // this lane's two cells (MFMA columns): tile 0 = board rows 0-3, tile 1 = rows 4-7
     const int cy[2] = {c >> 3, 4 + (c >> 3)}, cx = c & 7;
     uint32_t res[2][4][4][2];   // residual x, packed bf16 in the accumulator layout
@@ -151,33 +227,8 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
                     acc[1][nt][4 * q + i] = b[i];
                 }
             }
-        const int halves = (L == 0) ? 1 : 2;
-        for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            uint32_t cbase[2], csw[2];
-#pragma unroll
-            for (int tt = 0; tt < 2; tt++) {
-                const int sy = cy[tt] + dy, sx = cx + dx;
-                const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
-                const int sc = sy * 8 + sx;
-                cbase[tt] = ok ? (uint32_t)((wave * TW_CELLS + sc) * 256) : (uint32_t)TW_ZERO_OFF;
-                csw[tt] = ok ? (uint32_t)(sc & 15) : 0u;
-            }
-            for (int half = 0; half < halves; half++, chunk++) {
-                // my pieces of `chunk` have landed when at most the newer chunks' loads are outstanding
-                const int newer = min(3, n_chunks - 1 - chunk);
-                if (newer == 3) wait_vmcnt<12>();
-                else if (newer == 2) wait_vmcnt<8>();
-                else if (newer == 1) wait_vmcnt<4>();
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone finished chunk-1
-                asm volatile("" ::: "memory");
-                if (chunk + 4 < n_chunks)
-                    issue_chunk(weights + (size_t)(chunk + 4) * TW_CHUNK_BYTES, lds, (chunk + 4) % TW_NSLOT, wave, lane);
-                if (L == 0) compute_chunk<1>(acc, lds, chunk % TW_NSLOT, 0, cbase, csw, lane);
-                else compute_chunk<4>(acc, lds, chunk % TW_NSLOT, half, cbase, csw, lane);
-            }
-        }
+        if (L == 0) run_layer<1>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
+        else run_layer<4>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
         // ---- epilogue (wave-private: a wave reads and writes only its own board's cells)
         const bool conv2 = (L >= 2) && ((L & 1) == 0);   // second conv of a block: + residual
         const bool keep = (L == 0) || conv2;             // output is a block input x: keep it for the skip
