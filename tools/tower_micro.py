@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Micro-driver for the tower kernel: G boards, random-init 128x10 net, N launches (for rocprofv3 --pmc)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+import yinyang_game_alphazero_amd as pkg
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+torch.manual_seed(0)
+net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
+ev = pkg.BatchedEvaluator(net, "bf16")
+rng = np.random.default_rng(0)
+planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
+for _ in range(3):
+    pkg.engine.tower_forward(planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+torch.cuda.synchronize()
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(N):
+    pkg.engine.tower_forward(planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+t1.record(); torch.cuda.synchronize()
+ms = t0.elapsed_time(t1) / N
+fl = (2 * 9 * 16 * 128 * 64 + 20 * 2 * 9 * 128 * 128 * 64) * G
+print(f"tower G={G}: {ms*1e3:.1f} us/launch, {fl/ms/1e9:.1f} TFLOP/s")

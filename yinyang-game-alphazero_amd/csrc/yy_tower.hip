@@ -7,8 +7,8 @@
 // MI355X design.  A 3x3 convolution on an 8x8 board never looks outside its board, so the whole
 // tower of a board can run inside one workgroup with no inter-workgroup dependency:
 //   * workgroup = 4 waves = 4 boards (wave w owns board w: its 64 cells are the MFMA columns);
-//   * the boards' activations [64 cells][128 ch] bf16 live in LDS for ALL layers (64 KB, XOR-swizzled
-//     16-B slots so ds_read_b128 fragment reads are conflict-free); they never touch HBM;
+//   * the boards' activations [64 cells][128 ch] bf16 live in LDS for ALL layers (68 KB, rows padded by
+//     16 B so ds_read_b128 fragment reads are conflict-free and use immediate offsets); they never touch HBM;
 //   * each layer is an implicit GEMM  D[cout][cell] = sum_{tap,cin} W[cout][tap,cin] * X[cin][cell+tap]
 //     on v_mfma_f32_32x32x16_bf16 (weights = A operand, shifted activations = B operand; out-of-board
 //     taps read a zero row); a wave accumulates its full 128 x 64 output tile in 128 accumulator
@@ -17,12 +17,13 @@
 //   * weights stream L2 -> LDS with global_load_lds_dwordx4 through a 5-slot ring of 16 KB chunks
 //     (one chunk = one tap x 64 input channels, pre-packed on the host in fragment order), counted
 //     s_waitcnt vmcnt + raw s_barrier, 4 chunks (~2 taps of compute) in flight;
-//   * LDS: 64 KB activations + 80 KB ring + 12.25 KB bias table + zero row = 160 KB -> 1 workgroup/CU,
+//   * LDS: 68 KB activations (272-B padded rows) + 80 KB ring + 11.5 KB bias table + zero row = 160 KB -> 1 workgroup/CU,
 //     one wave per SIMD with the whole register file.
 // Roofline: MFMA (bf16 dense 2.5 PFLOP/s).  Algorithmic FLOPs per board: 2*9*16*128*64 (stem, K padded
 // to 16) + (layers-1) * 2*9*128*128*64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/yy_engine.h"
 
@@ -36,12 +37,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define TW_TB 4
 #define TW_CH 128
 #define TW_CELLS 64
-#define TW_ACT_BYTES (TW_TB * TW_CELLS * TW_CH * 2)        // 65536
+#define TW_ROW_BYTES 272                                   // 256 B of channels + 16 B pad: consecutive cells land on
+                                                           // consecutive 16-B bank slots (conflict-free b128 reads)
+#define TW_ACT_BYTES (TW_TB * TW_CELLS * TW_ROW_BYTES)     // 69632
 #define TW_CHUNK_BYTES 16384                               // [ks 4][ntile 4][h 2][c 32][j 8] bf16
 #define TW_NSLOT 5
 #define TW_RING_OFF TW_ACT_BYTES
 #define TW_BIAS_OFF (TW_RING_OFF + TW_NSLOT * TW_CHUNK_BYTES)   // 147456
-#define TW_MAX_LAYERS 24
+#define TW_MAX_LAYERS 23
 #define TW_ZERO_OFF (TW_BIAS_OFF + TW_MAX_LAYERS * TW_CH * 4)   // 159744, 256 B of zeros
 #define TW_LDS_BYTES 163840
 
@@ -53,12 +56,18 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     t[1] = (__bf16)b;
     return __builtin_bit_cast(uint32_t, t);
 }
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t relu_pk(uint32_t p) {   // max(x, 0) on two packed bf16 as signed int16
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
+}
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
 
 // byte offset of the 16-B slot holding channels [8*chunk, 8*chunk+8) of (board, cell)
 __device__ __forceinline__ uint32_t act_off(int board, int cell, int chunk) {
-    return (uint32_t)(((board * TW_CELLS + cell) * 16 + (chunk ^ (cell & 15))) * 16);
+    return (uint32_t)((board * TW_CELLS + cell) * TW_ROW_BYTES + chunk * 16);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -84,13 +93,13 @@ struct Frags {
     bf16x8 x[2], w[4];
 };
 __device__ __forceinline__ void load_frags(Frags &f, const unsigned char *lds, int slot, int half, int ks,
-                                           const uint32_t (&cbase)[2], const uint32_t (&csw)[2], int lane) {
+                                           const uint32_t (&cbase)[2], int lane) {
     const int h = lane >> 5, c = lane & 31;
-    const int cc = half * 8 + ks * 2 + h;   // 16-B channel slot this lane's fragment covers
+    // cbase already contains this lane's h*16; (half, ks) are compile-time after unrolling -> immediate offsets
     const unsigned char *wslot = lds + TW_RING_OFF + slot * TW_CHUNK_BYTES + (h * 32 + c) * 16 + ks * 4096;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
-        f.x[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + cbase[tt] + (((uint32_t)cc ^ csw[tt]) << 4)));
+        f.x[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + cbase[tt] + half * 128 + ks * 32));
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) f.w[nt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(wslot + nt * 1024));
 }
@@ -100,6 +109,15 @@ __device__ __forceinline__ void mma8(f32x16 (&acc)[2][4], const Frags &f) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
             acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nt], f.x[tt], acc[tt][nt], 0, 0, 0);
+}
+// first k-step of a layer: C = 0 (inline constant), no accumulator initialisation
+__device__ __forceinline__ void mma8_zero(f32x16 (&acc)[2][4], const Frags &f) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+            acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nt], f.x[tt], z, 0, 0, 0);
 }
 // issue order hint: the 6 LDS reads of the NEXT k-step interleaved with the 8 MFMAs of the current one
 __device__ __forceinline__ void interleave_hint() {
@@ -111,15 +129,14 @@ __device__ __forceinline__ void interleave_hint() {
     __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);       // 5 MFMAs cover the last reads' latency
 }
 // cell geometry of a tap for this lane's two cells: LDS row base and swizzle key (zero row when off-board)
-__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int wave, uint32_t (&cbase)[2], uint32_t (&csw)[2]) {
+__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int wave, int h, uint32_t (&cbase)[2]) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
         const int sy = cy[tt] + dy, sx = cx + dx;
         const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
         const int sc = sy * 8 + sx;
-        cbase[tt] = ok ? (uint32_t)((wave * TW_CELLS + sc) * 256) : (uint32_t)TW_ZERO_OFF;
-        csw[tt] = ok ? (uint32_t)(sc & 15) : 0u;
+        cbase[tt] = (ok ? (uint32_t)((wave * TW_CELLS + sc) * TW_ROW_BYTES) : (uint32_t)TW_ZERO_OFF) + (uint32_t)(h * 16);
     }
 }
 
@@ -127,14 +144,15 @@ __device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int
 // ring slot to every wave.  Each iteration first makes chunk+1 visible (counted vmcnt + barrier), refills
 // the slot chunk-1 used, then runs KS k-steps whose LDS reads are software-pipelined one k-step ahead,
 // across the chunk boundary too (only the first k-step of a layer exposes its read latency).
-template <int KS>
+template <int KS, int DBG>
 __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *lds, const unsigned char *weights, int &chunk,
                                           int n_chunks, const int (&cy)[2], int cx, int wave, int lane) {
     constexpr int NCH = (KS == 1) ? 9 : 18;
-    uint32_t cb[2], cs[2];
-    tap_geo(0, cy, cx, wave, cb, cs);
+    const int h = lane >> 5;
+    uint32_t cb[2];
+    tap_geo(0, cy, cx, wave, h, cb);
     Frags cur;
-    load_frags(cur, lds, chunk % TW_NSLOT, 0, 0, cb, cs, lane);
+    load_frags(cur, lds, chunk % TW_NSLOT, 0, 0, cb, lane);
     for (int i = 0; i < NCH; i++, chunk++) {
         const int half = (KS == 1) ? 0 : (i & 1);
         if (chunk + 1 < n_chunks) {
@@ -144,35 +162,34 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *ld
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();   // chunk+1 landed everywhere; everyone finished chunk-1
             asm volatile("" ::: "memory");
-            if (chunk + 4 < n_chunks)
+            if (chunk + 4 < n_chunks && !(DBG & 1))
                 issue_chunk(weights + (size_t)(chunk + 4) * TW_CHUNK_BYTES, lds, (chunk + 4) % TW_NSLOT, wave, lane);
         }
+        if constexpr ((DBG & 2) != 0) continue;   // experiment: weight stream + barriers only
         const bool last = (i == NCH - 1);
-        uint32_t ncb[2], ncs[2];
+        uint32_t ncb[2];
         const int ni = last ? i : i + 1;
-        tap_geo((KS == 1) ? ni : (ni >> 1), cy, cx, wave, ncb, ncs);
+        tap_geo((KS == 1) ? ni : (ni >> 1), cy, cx, wave, h, ncb);
         const int nhalf = (KS == 1) ? 0 : (ni & 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             Frags nxt;
-            if (ks + 1 < KS) {
-                load_frags(nxt, lds, chunk % TW_NSLOT, half, ks + 1, cb, cs, lane);
-                mma8(acc, cur);
+            const bool has_next = (ks + 1 < KS) || !last;
+            if (ks + 1 < KS) load_frags(nxt, lds, chunk % TW_NSLOT, half, ks + 1, cb, lane);
+            else if (!last) load_frags(nxt, lds, (chunk + 1) % TW_NSLOT, nhalf, 0, ncb, lane);
+            if (i == 0 && ks == 0) mma8_zero(acc, cur);
+            else mma8(acc, cur);
+            if (has_next) {
                 interleave_hint();
                 cur = nxt;
-            } else if (!last) {
-                load_frags(nxt, lds, (chunk + 1) % TW_NSLOT, nhalf, 0, ncb, ncs, lane);
-                mma8(acc, cur);
-                interleave_hint();
-                cur = nxt;
-            } else {
-                mma8(acc, cur);
             }
         }
-        cb[0] = ncb[0]; cb[1] = ncb[1]; cs[0] = ncs[0]; cs[1] = ncs[1];
+        cb[0] = ncb[0];
+        cb[1] = ncb[1];
     }
 }
 
+template <int DBG>
 __global__ void __launch_bounds__(256, 1)
 k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
         unsigned short *__restrict__ out, int G, int n_layers) {
@@ -215,48 +232,42 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
 
     for (int L = 0; L < n_layers; L++) {
         f32x16 acc[2][4];
-        // accumulators start at the bias: lane's rows of tile nt are couts nt*32 + 8q + 4h + i
+        if (L == 0) run_layer<1, DBG>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
+        else run_layer<4, DBG>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
+        if constexpr ((DBG & 4) != 0) {   // experiment: no epilogue (keep the accumulators alive)
+            asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]));
+            asm volatile("" ::"v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]));
+            continue;
+        }
+        // ---- epilogue (wave-private: a wave reads and writes only its own board's cells):
+        // + bias (+ residual), bf16 rounding, ReLU on the packed pair (v_pk_max_i16: bf16 is sign-magnitude)
+        const bool conv2 = (L >= 2) && ((L & 1) == 0);   // second conv of a block: + residual
+        const bool keep = (L == 0) || conv2;             // output is a block input x: keep it for the skip
 #pragma unroll
         for (int nt = 0; nt < 4; nt++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                // this lane's rows of tile nt are couts nt*32 + 8q + 4h + i
                 const f32x4 b = *(const f32x4 *)(lds + TW_BIAS_OFF + (L * TW_CH + nt * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    acc[0][nt][4 * q + i] = b[i];
-                    acc[1][nt][4 * q + i] = b[i];
-                }
-            }
-        if (L == 0) run_layer<1>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
-        else run_layer<4>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
-        // ---- epilogue (wave-private: a wave reads and writes only its own board's cells)
-        const bool conv2 = (L >= 2) && ((L & 1) == 0);   // second conv of a block: + residual
-        const bool keep = (L == 0) || conv2;             // output is a block input x: keep it for the skip
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++) {
-            const int cell = tt * 32 + c;
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float v0 = acc[tt][nt][4 * q + 0], v1 = acc[tt][nt][4 * q + 1];
-                    float v2 = acc[tt][nt][4 * q + 2], v3 = acc[tt][nt][4 * q + 3];
+                for (int tt = 0; tt < 2; tt++) {
+                    f32x2 v01 = {acc[tt][nt][4 * q + 0] + b[0], acc[tt][nt][4 * q + 1] + b[1]};
+                    f32x2 v23 = {acc[tt][nt][4 * q + 2] + b[2], acc[tt][nt][4 * q + 3] + b[3]};
                     if (conv2) {
-                        v0 += bf_lo(res[tt][nt][q][0]);
-                        v1 += bf_hi(res[tt][nt][q][0]);
-                        v2 += bf_lo(res[tt][nt][q][1]);
-                        v3 += bf_hi(res[tt][nt][q][1]);
+                        const uint32_t r0 = res[tt][nt][q][0], r1 = res[tt][nt][q][1];
+                        v01 += (f32x2){bf_lo(r0), bf_hi(r0)};
+                        v23 += (f32x2){bf_lo(r1), bf_hi(r1)};
                     }
-                    const uint32_t p0 = pack_bf16(fmaxf(v0, 0.0f), fmaxf(v1, 0.0f));
-                    const uint32_t p1 = pack_bf16(fmaxf(v2, 0.0f), fmaxf(v3, 0.0f));
+                    const uint32_t p0 = relu_pk(pack_bf16(v01[0], v01[1]));
+                    const uint32_t p1 = relu_pk(pack_bf16(v23[0], v23[1]));
                     if (keep) {
                         res[tt][nt][q][0] = p0;
                         res[tt][nt][q][1] = p1;
                     }
                     u32x2 pk = {p0, p1};
-                    *(u32x2 *)(lds + act_off(wave, cell, nt * 4 + q) + h * 8) = pk;
+                    *(u32x2 *)(lds + act_off(wave, tt * 32 + c, nt * 4 + q) + h * 8) = pk;
                 }
-        }
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // ---- final activations -> HBM, [board][cell][128] bf16 (channels-last), un-swizzled, 1 KiB per wave store
@@ -280,8 +291,20 @@ extern "C" int yy_nn_tower_bf16(const float *planes, const void *weights, const 
     if (!planes || !weights || !bias || !out || G < 0) return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_bf16: bad argument");
     if (R != 8 || C != 8 || channels != TW_CH || n_layers < 1 || n_layers > TW_MAX_LAYERS || (n_layers & 1) == 0)
         return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_bf16: needs 8x8 boards, 128 channels, 1 + 2*blocks <= 23 layers");
-    k_tower<<<dim3((G + TW_TB - 1) / TW_TB), dim3(256), 0, (hipStream_t)s>>>(planes, (const unsigned char *)weights, bias,
-                                                                           (unsigned short *)out, G, n_layers);
+    static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
+    const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
+    const unsigned char *w = (const unsigned char *)weights;
+    unsigned short *o = (unsigned short *)out;
+    hipStream_t st = (hipStream_t)s;
+    switch (dbg) {
+        case 1: k_tower<1><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 2: k_tower<2><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 4: k_tower<4><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 5: k_tower<5><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 6: k_tower<6><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 7: k_tower<7><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        default: k_tower<0><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+    }
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_bf16: launch failed");
     return YY_OK;
 }
