@@ -156,7 +156,10 @@ def roofline_pass(eng):
         tt = HipEventTimer(reps)
         for _ in range(reps):
             tt.start()
-            E.tower_forward(eng.ctx.planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+            if getattr(ev, "fused_heads", False):
+                E.tower_heads_forward(eng.ctx.planes, ev.towerh_w, ev.towerh_b, ev.tower_layers)
+            else:
+                E.tower_forward(eng.ctx.planes, ev.tower_w, ev.tower_b, ev.tower_layers)
             tt.stop()
         tower_ms, _ = tt.mean_ms()
     return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms
@@ -290,9 +293,10 @@ def main():
         if tower_ms is not None:
             # dominant kernel of a step = the LDS-resident MFMA tower (csrc/yy_tower.hip): algorithmic FLOPs per
             # board = stem with K padded to 16 + 2 convs per block, each 2*9*128*128*64
-            tower_flops = (2 * 9 * 16 * 128 * 64 + 2 * args.blocks * (2 * 9 * 128 * 128 * 64)) * args.games
+            tower_flops = (2 * 9 * 16 * 128 * 64 + 2 * args.blocks * (2 * 9 * 128 * 128 * 64)
+                           + (2 * 128 * 64 * 64 if getattr(eng.evaluator, "fused_heads", False) else 0)) * args.games
             ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_tower (stem + residual tower, bf16 MFMA, activations LDS-resident)",
+            roof = {"bound": "mfma", "kernel": "k_tower (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)",
                     "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": None, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
             extra["roofline_tree_kernel"] = roof_tree

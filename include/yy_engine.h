@@ -181,6 +181,15 @@ int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_
 int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G,
                      int R, int C, int channels, int n_layers, yy_stream_t stream);
 
+/* Same kernel, with the policy_conv / value_conv 1x1 head convolutions + BatchNorm + ReLU
+ * (neural_network.py:113, 118) fused behind the tower: out_heads bf16 [G,2,32,64] = [policy features,
+ * value features] in the reference's NCHW flatten order (channel*64 + cell, :114 / :119), ready for
+ * policy_fc / value_fc1.  weights holds one extra 16 KB chunk ([ks 8][nt 2][h 2][c 32][j 8]) and bias
+ * one extra row [n_layers] = [policy bias 32 | value bias 32 | 0...]. */
+int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float *bias,
+                           void *out_heads, int G, int R, int C, int channels, int n_layers,
+                           yy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

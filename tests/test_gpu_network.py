@@ -85,8 +85,9 @@ def test_tower_kernel_matches_torch_bf16_path():
         boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda()
         planes = pkg.engine.encode_planes(boards)
         ref = pkg.BatchedEvaluator(net, "bf16", tower=False)
-        tow = pkg.BatchedEvaluator(net, "bf16", tower=True)
-        assert tow.tower and not ref.tower
+        tow = pkg.BatchedEvaluator(net, "bf16", tower=True, fused_heads=False)
+        towh = pkg.BatchedEvaluator(net, "bf16", tower=True, fused_heads=True)
+        assert tow.tower and not ref.tower and towh.fused_heads
         # tower activations
         x_t = pkg.engine.tower_forward(planes, tow.tower_w, tow.tower_b, tow.tower_layers).float()
         x = planes.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -103,3 +104,13 @@ def test_tower_kernel_matches_torch_bf16_path():
         assert float((p_t - p_r).abs().max()) < 2e-2 and float((v_t - v_r).abs().max()) < 5e-2
         p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
         assert float((p_t - p32).abs().max()) < 2e-2 and float((v_t - v32).abs().max()) < 5e-2
+        # fused 1x1 head convolutions: features against torch ops on the tower kernel's own output (same
+        # input, so only summation order differs: 2 bf16 ulps of the feature scale), then end to end
+        feats = pkg.engine.tower_heads_forward(planes, towh.towerh_w, towh.towerh_b, towh.tower_layers).float()
+        xt = pkg.engine.tower_forward(planes, tow.tower_w, tow.tower_b, tow.tower_layers)
+        pf = tow._conv(xt, tow.phead, 0).contiguous().flatten(1).float()
+        vf = tow._conv(xt, tow.vhead, 0).contiguous().flatten(1).float()
+        fs = max(float(pf.abs().max()), float(vf.abs().max()))
+        assert float((feats[:, 0] - pf).abs().max()) <= fs * 2.0 ** -7 and float((feats[:, 1] - vf).abs().max()) <= fs * 2.0 ** -7
+        p_h, v_h = towh(planes)
+        assert float((p_h - p_t).abs().max()) < 2e-2 and float((v_h - v_t).abs().max()) < 5e-2

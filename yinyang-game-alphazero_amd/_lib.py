@@ -71,6 +71,7 @@ _SIGS = {
     "yy_mcts_reset_counters": [_vp, _vp],
     "yy_nn_bias_act_bf16": [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp],
     "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_version": [],
 }
 

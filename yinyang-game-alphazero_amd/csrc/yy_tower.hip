@@ -192,7 +192,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *ld
 template <int DBG>
 __global__ void __launch_bounds__(256, 1)
 k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
-        unsigned short *__restrict__ out, int G, int n_layers) {
+        unsigned short *__restrict__ out, unsigned short *__restrict__ out_heads, int G, int n_layers) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[TW_LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,7 +200,8 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
     const int h = lane >> 5, c = lane & 31;
 
     // ---- prologue: bias table + zero row + input planes -> LDS (ordinary loads, drained before the ring starts)
-    for (int i = threadIdx.x; i < n_layers * TW_CH; i += 256) ((float *)(lds + TW_BIAS_OFF))[i] = bias[i];
+    for (int i = threadIdx.x; i < (n_layers + (out_heads ? 1 : 0)) * TW_CH; i += 256)
+        ((float *)(lds + TW_BIAS_OFF))[i] = bias[i];
     if (threadIdx.x < 64) ((uint32_t *)(lds + TW_ZERO_OFF))[threadIdx.x] = 0u;
     {
         // lane = cell: 5 planes (neural_network.py:156-196) -> channels 0..4 of a 16-channel input, rest zero
@@ -214,7 +215,8 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-    const int n_chunks = 9 + 18 * (n_layers - 1);
+    // the policy/value 1x1 head convolutions ride the same ring as one extra 16 KB chunk after the tower
+    const int n_chunks = 9 + 18 * (n_layers - 1) + (out_heads ? 1 : 0);
 #pragma unroll
     for (int pc = 0; pc < 4; pc++)
         if (pc < n_chunks) issue_chunk(weights + (size_t)pc * TW_CHUNK_BYTES, lds, pc % TW_NSLOT, wave, lane);
@@ -270,7 +272,61 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // ---- final activations -> HBM, [board][cell][128] bf16 (channels-last), un-swizzled, 1 KiB per wave store
+    if (out_heads) {
+        // ---- policy_conv / value_conv (1x1, 128 -> 32 each; neural_network.py:59-60, 65-66, 113, 118) + bias + ReLU
+        // chunk layout [ks 8][nt 2][h 2][c 32][j 8]: nt 0 = policy channels, nt 1 = value channels
+        const unsigned char *hw = lds + TW_RING_OFF + (chunk % TW_NSLOT) * TW_CHUNK_BYTES + (h * 32 + c) * 16;
+        const uint32_t xb[2] = {(uint32_t)((wave * TW_CELLS + c) * TW_ROW_BYTES + h * 16),
+                                (uint32_t)((wave * TW_CELLS + 32 + c) * TW_ROW_BYTES + h * 16)};
+        f32x16 hacc[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            bf16x8 xf[2], wf[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) xf[tt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(lds + xb[tt] + ks * 32));
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) wf[nt] = __builtin_bit_cast(bf16x8, *(const u32x4 *)(hw + (ks * 2 + nt) * 1024));
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    if (ks == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        hacc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[tt], z, 0, 0, 0);
+                    } else {
+                        hacc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[tt], hacc[tt][nt], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // stage [head][channel 32][cell 64] bf16 (the reference's NCHW flatten order, :114/:119) in this wave's
+        // own (now dead) activation rows, then stream it out 1 KiB per wave store
+        unsigned char *stg = lds + wave * TW_CELLS * TW_ROW_BYTES;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b = *(const f32x4 *)(lds + TW_BIAS_OFF + (n_layers * TW_CH + nt * 32 + 8 * q + 4 * h) * 4);
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float v = fmaxf(hacc[tt][nt][4 * q + i] + b[i], 0.0f);
+                        const int ch = 8 * q + 4 * h + i, cell = tt * 32 + c;
+                        *(unsigned short *)(stg + ((nt * 32 + ch) * TW_CELLS + cell) * 2) = (unsigned short)(pack_bf16(v, 0.0f) & 0xFFFFu);
+                    }
+            }
+        __syncthreads();
+        if (gb < G) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const u32x4 v = *(const u32x4 *)(stg + (i * 64 + lane) * 16);
+                *(u32x4 *)(out_heads + (size_t)gb * 4096 + (i * 64 + lane) * 8) = v;
+            }
+        }
+        return;
+    }
+    // ---- final activations -> HBM, [board][cell][128] bf16 (channels-last), 1 KiB per wave store
     __syncthreads();
     if (gb < G) {
         const int ch = lane & 15;
@@ -283,28 +339,39 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
     }
 }
 
-// weights: bf16 chunks [9 + 18*(n_layers-1)][8192] in fragment order (network.pack_tower);
-// bias f32 [n_layers][128]; planes f32 [G,5,8,8]; out bf16 [G,8,8,128].
-extern "C" int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G, int R,
-                                int C, int channels, int n_layers, yy_stream_t s) {
+// weights: bf16 chunks [9 + 18*(n_layers-1) (+1 head chunk)][8192] in fragment order (network.pack_tower);
+// bias f32 [n_layers (+1)][128]; planes f32 [G,5,8,8]; out bf16 [G,8,8,128] or out_heads bf16 [G,2,32,64].
+static int launch_tower(const float *planes, const void *weights, const float *bias, void *out, void *out_heads, int G,
+                        int R, int C, int channels, int n_layers, yy_stream_t s) {
     if (G == 0) return YY_OK;
-    if (!planes || !weights || !bias || !out || G < 0) return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_bf16: bad argument");
-    if (R != 8 || C != 8 || channels != TW_CH || n_layers < 1 || n_layers > TW_MAX_LAYERS || (n_layers & 1) == 0)
-        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_bf16: needs 8x8 boards, 128 channels, 1 + 2*blocks <= 23 layers");
+    if (!planes || !weights || !bias || (!out && !out_heads) || G < 0)
+        return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower: bad argument");
+    if (R != 8 || C != 8 || channels != TW_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > TW_MAX_LAYERS || (n_layers & 1) == 0)
+        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 8x8 boards, 128 channels, at most 10 residual blocks");
     static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
     const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
     const unsigned char *w = (const unsigned char *)weights;
-    unsigned short *o = (unsigned short *)out;
+    unsigned short *o = (unsigned short *)out, *oh = (unsigned short *)out_heads;
     hipStream_t st = (hipStream_t)s;
     switch (dbg) {
-        case 1: k_tower<1><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        case 2: k_tower<2><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        case 4: k_tower<4><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        case 5: k_tower<5><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        case 6: k_tower<6><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        case 7: k_tower<7><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
-        default: k_tower<0><<<grid, block, 0, st>>>(planes, w, bias, o, G, n_layers); break;
+        case 1: k_tower<1><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 2: k_tower<2><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 4: k_tower<4><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 5: k_tower<5><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 6: k_tower<6><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 7: k_tower<7><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        default: k_tower<0><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
     }
-    if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_bf16: launch failed");
+    if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower: launch failed");
     return YY_OK;
+}
+
+extern "C" int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G, int R,
+                                int C, int channels, int n_layers, yy_stream_t s) {
+    return launch_tower(planes, weights, bias, out, nullptr, G, R, C, channels, n_layers, s);
+}
+
+extern "C" int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float *bias, void *out_heads, int G,
+                                      int R, int C, int channels, int n_layers, yy_stream_t s) {
+    return launch_tower(planes, weights, bias, nullptr, out_heads, G, R, C, channels, n_layers, s);
 }

@@ -154,6 +154,19 @@ def pack_tower(net):
     return wq, torch.stack(biases).contiguous()
 
 
+def pack_heads(net):
+    """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
+    [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
+    and one extra bias row [policy 32 | value 32 | zeros]."""
+    wp, bp = fold_batchnorm(net.policy_conv, net.policy_bn)      # [32,128,1,1]
+    wv, bv = fold_batchnorm(net.value_conv, net.value_bn)
+    w = torch.cat([wp, wv]).float().cpu().reshape(2, 32, 8, 2, 8)   # nt, c, ks, h, j
+    chunk = w.permute(2, 0, 3, 1, 4).contiguous().reshape(1, -1)    # ks, nt, h, c, j
+    bias = torch.zeros(1, 128)
+    bias[0, :32], bias[0, 32:64] = bp.float().cpu(), bv.float().cpu()
+    return chunk.to(torch.bfloat16).view(torch.int16).contiguous(), bias
+
+
 class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
@@ -165,7 +178,7 @@ class BatchedEvaluator:
     the 3-4 elementwise kernels PyTorch would launch.
     """
 
-    def __init__(self, net, mode="fp32", fused_epilogue=True, tower=True):
+    def __init__(self, net, mode="fp32", fused_epilogue=True, tower=True, fused_heads=True):
         self.net = net.eval()
         self.mode = mode
         self.device = next(net.parameters()).device
@@ -181,6 +194,11 @@ class BatchedEvaluator:
             wq, bq = pack_tower(net)
             self.tower_w, self.tower_b = wq.to(self.device), bq.to(self.device)
             self.tower_layers = 1 + 2 * len(net.res_blocks)
+            self.fused_heads = bool(fused_heads) and net.policy_conv.out_channels == 32
+            if self.fused_heads:
+                hw, hb = pack_heads(net)
+                self.towerh_w = torch.cat([wq, hw]).contiguous().to(self.device)
+                self.towerh_b = torch.cat([bq, hb]).contiguous().to(self.device)
 
     def _fold(self):
         n, dt = self.net, self.dtype
@@ -212,6 +230,13 @@ class BatchedEvaluator:
     def __call__(self, planes):
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
+        if self.tower and self.fused_heads:
+            from . import engine
+            feats = engine.tower_heads_forward(planes, self.towerh_w, self.towerh_b, self.tower_layers)
+            logits = F.linear(feats[:, 0], *self.pfc).float()
+            hdn = F.relu(F.linear(feats[:, 1], *self.vfc1)).float()
+            value = torch.tanh(F.linear(hdn, *self.vfc2)).reshape(-1)
+            return F.softmax(logits, dim=1), value
         if self.tower:
             from . import engine
             x = engine.tower_forward(planes, self.tower_w, self.tower_b, self.tower_layers)
