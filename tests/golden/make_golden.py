@@ -14,6 +14,7 @@ Fixture families:
                            semantics, several simulation counts, optional root noise
      search_net_8x8.npz    MCTS.search with the real seeded 128x10 net, evaluator outputs recorded
   G4 episodes.npz          SelfPlayWorker.play_game transcripts (literal and copied adapter)
+  G6 augment.npz           DataProcessor.augment_sample: the 8 symmetric (planes, policy) variants
 
 The reference imports create mcts.log / neural_network.log / training.log in the
 CWD, so run from a scratch directory.  Nothing is written into the reference tree.
@@ -474,9 +475,45 @@ def gen_g4(pool):
         print("wrote", path, "games", len(sel), "examples per game", out["n"].tolist(), flush=True)
 
 
+# --------------------------------------------------------------------------- G6 augmentation
+def gen_g6():
+    """DataProcessor.augment_sample (data_utils.py:39-134): the 8 (planes, policy) variants, in order."""
+    import torch
+    YinYangGame, YinYangLogic, _ = _import_ref()
+    from src.yin_yang.ai.neural_network import YinYangNeuralNetwork
+    from src.yin_yang.ai.data_utils import DataProcessor
+    out = {}
+    for (R, C) in ((6, 6), (8, 8)):
+        game = YinYangGame(R, C)
+        net = YinYangNeuralNetwork(game, num_channels=8, num_res_blocks=1)
+        proc = DataProcessor(game)
+        rng = np.random.default_rng(600 + R)
+        boards, pis, aug_planes, aug_pis = [], [], [], []
+        for _ in range(8):
+            arr, _pl = random_play_positions(game, rng, 1)[0]
+            lb = YinYangLogic(R, C)
+            lb.board = arr.copy()
+            pi = rng.random(R * C) * (rng.random(R * C) < 0.4)
+            pi = pi / max(pi.sum(), 1e-9)
+            planes = net.board_to_input(lb)
+            aug = proc.augment_sample(planes, torch.FloatTensor(pi))
+            assert len(aug) == 8
+            boards.append(arr)
+            pis.append(pi.astype(np.float32))
+            aug_planes.append(np.stack([a[0].numpy() for a in aug]))
+            aug_pis.append(np.stack([np.asarray(a[1], dtype=np.float32) for a in aug]))
+        out[f"boards_{R}"] = np.stack(boards).astype(np.int8)
+        out[f"pi_{R}"] = np.stack(pis)
+        out[f"aug_planes_{R}"] = np.stack(aug_planes).astype(np.float32)
+        out[f"aug_pi_{R}"] = np.stack(aug_pis).astype(np.float32)
+    path = os.path.join(OUT, "augment.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g3net,g4")
+    ap.add_argument("--only", default="g1,g2,g3,g3net,g4,g6")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--n-rules", type=int, default=10240)
     args = ap.parse_args()
@@ -494,6 +531,8 @@ def main():
         gen_g3_net(pool)
     if "g4" in only:
         gen_g4(pool)
+    if "g6" in only:
+        gen_g6()
     pool.close()
 
 

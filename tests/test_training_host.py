@@ -1,0 +1,74 @@
+"""CPU tests of the training-side widening: 8-fold augmentation against the
+reference's DataProcessor.augment_sample (G6 fixture, exact), the replay queue, and the trainer on a
+tiny CPU network (loss decreases, reference checkpoint format)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_augment_batch_matches_reference():
+    from yinyang_game_alphazero_amd.training import augment_batch
+    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    for R in (6, 8):
+        boards, pi = z[f"boards_{R}"], z[f"pi_{R}"]
+        planes = torch.from_numpy(O.encode_planes(boards))
+        ap, api = augment_batch(planes, torch.from_numpy(pi))
+        N = boards.shape[0]
+        want_p, want_pi = z[f"aug_planes_{R}"], z[f"aug_pi_{R}"]      # [N, 8, ...]
+        for v in range(8):
+            assert np.array_equal(ap[v * N:(v + 1) * N].numpy(), want_p[:, v]), (R, v)
+            assert np.array_equal(api[v * N:(v + 1) * N].numpy(), want_pi[:, v]), (R, v)
+
+
+def test_training_data_queue(tmp_path):
+    from yinyang_game_alphazero_amd.training import TrainingDataQueue
+    q = TrainingDataQueue(max_size=10, sample_size=4)
+    assert len(q) == 0 and q.sample() == {}
+    ex = dict(states=torch.zeros((7, 4, 4), dtype=torch.int8), policies=torch.full((7, 16), 1 / 16.0),
+              values=torch.arange(7, dtype=torch.float32))
+    q.push_examples(ex)
+    q.push_examples(ex)
+    assert len(q) == 10 and q.values.tolist() == [4, 5, 6, 0, 1, 2, 3, 4, 5, 6]     # newest max_size kept
+    s = q.sample()
+    assert s["states"].shape == (4, 4, 4) and len(set(s["values"].tolist())) <= 4
+    path = tmp_path / "self_play_data_1.npz"
+    np.savez(path, boards=np.zeros((3, 4, 4), np.int8), states=np.zeros((3, 4, 4), np.int8),
+             policies=np.full((3, 16), 1 / 16.0), values=np.ones(3))
+    q2 = TrainingDataQueue()
+    q2.push_file(str(path))
+    q2.push_file(str(tmp_path / "missing.npz"))
+    assert len(q2) == 3
+
+
+def test_trainer_cpu_loss_decreases_and_checkpoints(tmp_path):
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(4, 4)
+    tr = pkg.AlphaZeroTrainer(game, model_dir=str(tmp_path), device="cpu", num_channels=8, num_res_blocks=1, batch_size=16)
+    rng = np.random.default_rng(0)
+    states = rng.integers(-1, 2, size=(24, 4, 4)).astype(np.int8)
+    pol = rng.random((24, 16)).astype(np.float32)
+    pol /= pol.sum(1, keepdims=True)
+    val = np.sign(states.sum((1, 2))).astype(np.float32)
+    ex = dict(states=torch.from_numpy(states), policies=torch.from_numpy(pol), values=torch.from_numpy(val))
+    m = tr.train(ex, epochs=6, augment=True)
+    assert len(m["total_loss"]) == 6 and m["total_loss"][-1] < m["total_loss"][0]
+    assert abs(m["total_loss"][0] - (m["policy_loss"][0] + m["value_loss"][0])) < 1e-5
+    tr.save_checkpoint(iteration=3)
+    ck = torch.load(str(tmp_path / "checkpoint_3.pth.tar"), map_location="cpu", weights_only=True)
+    assert set(ck) == {"state_dict", "board_size", "action_size"}
+    # pipeline resumes from the highest checkpoint_<n> (training_pipeline.py:171-190)
+    np.savez(tmp_path / "self_play_data_7.npz", boards=states, states=states, policies=pol.astype(np.float64), values=val.astype(np.float64))
+    pipe = pkg.TrainingPipeline(game, model_dir=str(tmp_path), data_dir=str(tmp_path), device="cpu", num_channels=8,
+                                num_res_blocks=1, epochs_per_iteration=1, checkpoint_interval=1)
+    assert pipe.iteration == 3
+    pipe.load_data()
+    assert len(pipe.data_queue) == 24
+    pipe.train_iteration()
+    assert os.path.exists(tmp_path / "checkpoint_4.pth.tar")

@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_alphazero.py --mode self-play ...
 
 Flags added to the reference's set: --concurrent-games, --board-semantics {copied,aliased},
---reference-quirks, --nn {bf16,fp32}, --seed.  `--mode train` / `--mode evaluate` (orchestration,
-trainer, arena: SURVEY.md 8f-2/3) are outside the hot path this repository covers.
+--reference-quirks, --nn {bf16,fp32}, --seed, --arena-games, --channels, --blocks.  `--mode train` runs
+the iteration loop (GPU self-play -> PyTorch-ROCm training -> batched arena -> promote at 0.6) and
+`--mode evaluate` plays 10 games against RandomPlayer, like the reference's modes.
 """
 import argparse
 import json
@@ -41,6 +42,9 @@ def parse_args(argv=None):
     p.add_argument("--reference-quirks", action="store_true", help="reproduce Q4/Q5 of the reference's play_game")
     p.add_argument("--nn", choices=["bf16", "fp32"], default="bf16")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--arena-games", type=int, default=40)
+    p.add_argument("--channels", type=int, default=128)
+    p.add_argument("--blocks", type=int, default=10)
     return p.parse_args(argv)
 
 
@@ -60,16 +64,30 @@ def main(argv=None):
     game = pkg.YinYangGame(args.rows, args.cols)
     for d in (args.model_dir, args.data_dir):
         os.makedirs(d, exist_ok=True)
-    if args.mode != "self-play":
-        sys.exit(f"--mode {args.mode}: orchestration/trainer/arena are outside this repository's hot-path scope "
-                 "(SURVEY.md 8f); use --mode self-play")
+    if args.mode == "train":                     # train_alphazero.py:84-101
+        az = pkg.AlphaZero(game, args.model_dir, args.data_dir, num_iterations=args.iterations, num_episodes=args.episodes,
+                           num_simulations=args.simulations, num_epochs=args.epochs, num_workers=args.workers,
+                           mcts_threads=args.mcts_threads, nn_mode=args.nn, concurrent_games=args.concurrent_games,
+                           arena_games=args.arena_games, num_channels=args.channels, num_res_blocks=args.blocks)
+        hist = az.run()
+        if rank == 0:
+            print(json.dumps({"iterations": hist}))
+        return
     model_path = os.path.join(args.model_dir, args.output_model)
+    if args.mode == "evaluate":                  # train_alphazero.py:124-243: 10 games against RandomPlayer
+        if not os.path.exists(model_path):
+            sys.exit(f"Model file not found: {model_path}")
+        res = pkg.evaluate_vs_random(game, model_path, num_games=10, num_simulations=args.simulations, nn_mode=args.nn,
+                                     num_channels=args.channels, num_res_blocks=args.blocks)
+        print(json.dumps(res))
+        return
     if not os.path.exists(model_path):           # same contract as the reference (train_alphazero.py:107-109)
         sys.exit(f"Model file not found: {model_path}")
     path = pkg.generate_self_play_data(game, model_path, args.data_dir, num_games=args.episodes,
                                        num_workers=args.workers, num_simulations=args.simulations,
                                        concurrent_games=args.concurrent_games, board_semantics=args.board_semantics,
-                                       reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed)
+                                       reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed,
+                                       num_channels=args.channels, num_res_blocks=args.blocks)
     if rank == 0:
         st = pkg.generate_self_play_data.last_stats
         st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])

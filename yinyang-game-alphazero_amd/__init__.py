@@ -20,6 +20,10 @@ def __getattr__(name):
         "MCTS": ".mcts", "Node": ".mcts",
         "SelfPlayWorker": ".self_play", "SelfPlayManager": ".self_play",
         "generate_self_play_data": ".self_play", "SelfPlayEngine": ".self_play",
+        "training": ".training", "AlphaZeroTrainer": ".training", "TrainingDataQueue": ".training",
+        "TrainingPipeline": ".training", "run_training_pipeline": ".training", "augment_batch": ".training",
+        "arena": ".arena", "Arena": ".arena", "AlphaZero": ".arena", "AlphaZeroPlayer": ".arena",
+        "RandomPlayer": ".arena", "evaluate_vs_random": ".arena",
     }
     if name in table:
         mod = importlib.import_module(table[name], __name__)

@@ -1,0 +1,252 @@
+"""Arena / evaluation and the iteration orchestrator.
+
+Mirrors src/yin_yang/ai/alphazero.py (AlphaZero :20-270, AlphaZeroPlayer :272-365),
+src/yin_yang/yin_yang_players.py (RandomPlayer :5-42) and the `evaluate` mode of
+train_alphazero.py:124-243.  Matches run batched on the same HIP engine: every game of a match is a
+slot of one lockstep batch, the two networks share the batch through `DualEvaluator` (each row is
+routed to the network whose turn it is), moves are arg-max of the visit counts (temperature 0) with
+the REAL side to move as root player and copied boards.
+
+Scoring note.  The reference scores a finished game with `getGameEnded(board, player)` for the player
+who would move NEXT and reads +1 as "first player won" (alphazero.py:206-218), which mis-attributes
+the winner whenever the loser is to move; here the winner is the colour with more stones
+(yin_yang_game.py:98-107), attributed to whichever network played that colour.
+"""
+import os
+import shutil
+
+import numpy as np
+import torch
+
+from . import engine
+from .mcts import MCTS
+from .network import BatchedEvaluator, YinYangNeuralNetwork
+from .self_play import LockstepSearch, generate_self_play_data
+from .training import run_training_pipeline
+
+
+class DualEvaluator:
+    """Routes each row of the leaf batch to evaluator A or B (fixed during one search)."""
+
+    def __init__(self, ev_a, ev_b, G, A, device):
+        self.ev_a, self.ev_b = ev_a, ev_b
+        self.idx_a = self.idx_b = None
+        self.policy = torch.zeros((G, A), dtype=torch.float32, device=device)
+        self.value = torch.zeros(G, dtype=torch.float32, device=device)
+
+    def assign(self, a_rows):
+        self.idx_a = a_rows.nonzero(as_tuple=True)[0]
+        self.idx_b = (~a_rows).nonzero(as_tuple=True)[0]
+
+    def __call__(self, planes):
+        for idx, ev in ((self.idx_a, self.ev_a), (self.idx_b, self.ev_b)):
+            if idx.numel():
+                p, v = ev(planes.index_select(0, idx).contiguous())
+                self.policy.index_copy_(0, idx, p)
+                self.value.index_copy_(0, idx, v)
+        return self.policy, self.value
+
+
+def _uniform_evaluator(A):
+    def ev(planes):
+        g = planes.shape[0]
+        return torch.full((g, A), 1.0 / A, device=planes.device), torch.zeros(g, device=planes.device)
+    return ev
+
+
+class Arena:
+    """num_games games between two players on one GPU.  A player is a batched evaluator
+    (planes -> policy, value) searched with `num_simulations`, or the string "random" (uniformly random
+    legal moves, RandomPlayer)."""
+
+    def __init__(self, game, player_a, player_b, num_simulations=800, cpuct=1.0, device=None, seed=0):
+        self.game = game
+        self.R, self.C = game.getBoardSize()
+        self.A = self.R * self.C
+        self.pa, self.pb, self.sims, self.cpuct = player_a, player_b, num_simulations, cpuct
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.rowcol = bool(getattr(game, "rowcol_rule", False))
+
+    def play(self, num_games):
+        """Returns dict(a_wins, b_wins, draws).  Game i: A plays black iff i is even (alphazero.py:177-186)."""
+        G, dev = int(num_games), self.device
+        boards = torch.zeros((G, self.R, self.C), dtype=torch.int8, device=dev)
+        players = torch.ones(G, dtype=torch.int8, device=dev)
+        a_is_black = (torch.arange(G, device=dev) % 2 == 0)
+        alive = torch.ones(G, dtype=torch.bool, device=dev)
+        ev_a = _uniform_evaluator(self.A) if self.pa == "random" else self.pa
+        ev_b = _uniform_evaluator(self.A) if self.pb == "random" else self.pb
+        dual = DualEvaluator(ev_a, ev_b, G, self.A, dev)
+        ctx = engine.BatchedMCTS(G, self.R, self.C, max(1, self.sims), cpuct=self.cpuct, rowcol=self.rowcol, device=dev)
+        search = LockstepSearch(ctx, dual, use_graph=False)     # the row routing changes every move
+        result = torch.zeros(G, dtype=torch.int8, device=dev)   # +1 black won, -1 white won, 2 draw
+        for _ in range(4 * self.A + 8):
+            if not bool(alive.any()):
+                break
+            mask = engine.valid_mask(boards, players, self.rowcol)
+            has = mask.bool().any(1)
+            # a side without a move passes; when neither side can move the game is over (scored below)
+            players = torch.where(alive & ~has, -players, players).contiguous()
+            mask = engine.valid_mask(boards, players, self.rowcol)
+            has = mask.bool().any(1)
+            movers = alive & has
+            a_to_move = (players == 1) == a_is_black
+            rand_rows = torch.zeros(G, dtype=torch.bool, device=dev)
+            if self.pa == "random":
+                rand_rows |= a_to_move
+            if self.pb == "random":
+                rand_rows |= ~a_to_move
+            action = torch.full((G,), -1, dtype=torch.int32, device=dev)
+            srch = movers & ~rand_rows
+            if bool(srch.any()):
+                dual.assign(a_to_move)
+                search.run(boards, players, self.sims, noise=None, active=srch.to(torch.uint8))
+                pi = ctx.root_policy(temperature_zero=True)          # select_action(temperature=0), :192-195
+                pick = torch.multinomial(torch.where(srch[:, None], pi, torch.full_like(pi, 1.0 / self.A)).float(), 1,
+                                         generator=self.gen).reshape(-1).to(torch.int32)
+                action = torch.where(srch, pick, action)
+            rnd = movers & rand_rows
+            if bool(rnd.any()):
+                m = torch.where(rnd[:, None], mask.float(), torch.full((G, self.A), 1.0, device=dev))
+                pick = torch.multinomial(m, 1, generator=self.gen).reshape(-1).to(torch.int32)
+                action = torch.where(rnd, pick, action)
+            old = players.clone()
+            engine.step_(boards, players, action.contiguous(), self.rowcol)
+            players = torch.where(movers, players, old).contiguous()
+            ended, counts = engine.game_ended(boards, players, self.rowcol, with_counts=True)
+            over = alive & (ended != 0)
+            diff = (counts[:, 0] - counts[:, 1])
+            res = torch.where(diff > 0, 1, torch.where(diff < 0, -1, 2)).to(torch.int8)
+            result = torch.where(over, res, result)
+            alive &= ~over
+        ctx.status()
+        ctx.close()
+        black_won, white_won = (result == 1), (result == -1)
+        a_wins = int(((black_won & a_is_black) | (white_won & ~a_is_black)).sum())
+        b_wins = int(((black_won & ~a_is_black) | (white_won & a_is_black)).sum())
+        return dict(a_wins=a_wins, b_wins=b_wins, draws=G - a_wins - b_wins, games=G)
+
+
+class RandomPlayer:
+    """yin_yang_players.py:5-42 (without the print)."""
+
+    def __init__(self, game):
+        self.game = game
+
+    def play(self, board, player):
+        idx = np.where(self.game.getValidMoves(board, player) == 1)[0]
+        return -1 if len(idx) == 0 else int(np.random.choice(idx))
+
+
+class AlphaZeroPlayer:
+    """alphazero.py:272-365: network + MCTS behind `play(board, player) -> action` (-1 = no move)."""
+
+    def __init__(self, game, model_path, num_simulations=800, num_threads=1, device=None):
+        self.game = game
+        net = YinYangNeuralNetwork(game)
+        if os.path.exists(model_path):
+            net.load_model(model_path)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.neural_net = net.to(dev).eval()
+        self.mcts = MCTS(game, self.neural_net, num_simulations=num_simulations, num_threads=num_threads,
+                         board_semantics="copied", device=dev)
+        self.root = None
+
+    def reset(self):
+        self.root = None
+
+    def play(self, board, player):
+        valid = self.game.getValidMoves(board, player)
+        if np.sum(valid) == 0:
+            return -1
+        return int(self.mcts.select_action(board, player, temperature=0, valid_moves=valid))
+
+
+def _load_evaluator(game, path, device, nn_mode, num_channels, num_res_blocks):
+    net = YinYangNeuralNetwork(game, num_channels, num_res_blocks)
+    net.load_model(path)
+    return BatchedEvaluator(net.to(device).eval(), nn_mode)
+
+
+class AlphaZero:
+    """Iteration loop (alphazero.py:20-270): self_play(best) -> train -> evaluate(current vs best) ->
+    promote at win ratio >= update_threshold; same file names (current_model / best_model /
+    checkpoint_<n>.pth.tar)."""
+
+    def __init__(self, game, model_dir="models", data_dir="data", num_iterations=100, num_episodes=100,
+                 num_simulations=800, num_epochs=10, temperature_threshold=10, update_threshold=0.6, num_workers=1,
+                 mcts_threads=1, arena_games=40, nn_mode="bf16", num_channels=128, num_res_blocks=10,
+                 concurrent_games=4096, device=None):
+        self.game, self.model_dir, self.data_dir = game, model_dir, data_dir
+        self.num_iterations, self.num_episodes, self.num_simulations = num_iterations, num_episodes, num_simulations
+        self.num_epochs, self.temperature_threshold, self.update_threshold = num_epochs, temperature_threshold, update_threshold
+        self.num_workers, self.mcts_threads, self.arena_games = num_workers, mcts_threads, arena_games
+        self.nn_mode, self.num_channels, self.num_res_blocks = nn_mode, num_channels, num_res_blocks
+        self.concurrent_games = concurrent_games
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        for d in (model_dir, data_dir):
+            os.makedirs(d, exist_ok=True)
+        self.current_model_path = os.path.join(model_dir, "current_model.pth.tar")
+        self.best_model_path = os.path.join(model_dir, "best_model.pth.tar")
+        if not os.path.exists(self.current_model_path):
+            YinYangNeuralNetwork(game, num_channels, num_res_blocks).save_model(self.current_model_path)
+        if not os.path.exists(self.best_model_path):
+            shutil.copy(self.current_model_path, self.best_model_path)
+        self.history = []
+
+    def self_play(self, model_path):
+        return generate_self_play_data(self.game, model_path, self.data_dir, num_games=self.num_episodes,
+                                       num_workers=self.num_workers, num_simulations=self.num_simulations,
+                                       temperature_threshold=self.temperature_threshold, nn_mode=self.nn_mode,
+                                       num_channels=self.num_channels, num_res_blocks=self.num_res_blocks,
+                                       concurrent_games=self.concurrent_games, seed=len(self.history))
+
+    def train(self):
+        # the reference passes num_iterations=1 and ignores --epochs (alphazero.py:120-127); epochs are honoured here
+        new_path = run_training_pipeline(self.game, self.model_dir, self.data_dir, num_iterations=1, sample_size=10000,
+                                         checkpoint_interval=1, epochs_per_iteration=self.num_epochs, device=self.device,
+                                         num_channels=self.num_channels, num_res_blocks=self.num_res_blocks)
+        shutil.copy(new_path, self.current_model_path)
+        return self.current_model_path
+
+    def evaluate(self, current_model_path, best_model_path, num_games=None):
+        n = self.arena_games if num_games is None else num_games
+        cur = _load_evaluator(self.game, current_model_path, self.device, self.nn_mode, self.num_channels, self.num_res_blocks)
+        best = _load_evaluator(self.game, best_model_path, self.device, self.nn_mode, self.num_channels, self.num_res_blocks)
+        res = Arena(self.game, cur, best, self.num_simulations, device=self.device, seed=len(self.history)).play(n)
+        self.last_arena = res
+        return res["a_wins"] / n
+
+    def update_best_model(self, win_ratio):
+        if win_ratio >= self.update_threshold:
+            shutil.copy(self.current_model_path, self.best_model_path)
+            return True
+        return False
+
+    def run(self):
+        import time
+        for it in range(self.num_iterations):
+            t0 = time.perf_counter()
+            data_file = self.self_play(self.best_model_path)
+            t1 = time.perf_counter()
+            self.train()
+            t2 = time.perf_counter()
+            ratio = self.evaluate(self.current_model_path, self.best_model_path)
+            t3 = time.perf_counter()
+            promoted = self.update_best_model(ratio)
+            self.history.append(dict(iteration=it + 1, data_file=data_file, self_play_s=t1 - t0, train_s=t2 - t1,
+                                     arena_s=t3 - t2, win_ratio=ratio, promoted=promoted, arena=self.last_arena,
+                                     losses=run_training_pipeline.last["metrics"]["total_loss"]))
+        return self.history
+
+
+def evaluate_vs_random(game, model_path, num_games=10, num_simulations=800, nn_mode="bf16", device=None,
+                       num_channels=128, num_res_blocks=10):
+    """`--mode evaluate` (train_alphazero.py:124-243): the model against RandomPlayer, alternating colours."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ev = _load_evaluator(game, model_path, dev, nn_mode, num_channels, num_res_blocks)
+    res = Arena(game, ev, "random", num_simulations, device=dev).play(num_games)
+    return dict(alphazero_wins=res["a_wins"], random_wins=res["b_wins"], draws=res["draws"],
+                win_rate=res["a_wins"] / num_games)

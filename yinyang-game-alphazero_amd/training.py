@@ -1,0 +1,234 @@
+"""Replay data, augmentation and the trainer.
+
+Mirrors src/yin_yang/ai/data_utils.py (DataProcessor.augment_sample :39-134),
+ai/training_pipeline.py (TrainingDataQueue :23-106, TrainingPipeline :108-291,
+run_training_pipeline :293-329) and ai/trainer.py (AlphaZeroTrainer :15-212) with the same names,
+hyper-parameters (Adam lr 1e-3, weight decay 1e-4, batch 64, soft-target cross-entropy + MSE) and
+checkpoint names (`checkpoint_<n>.pth.tar`, reference dict format), on tensors instead of pickled
+objects: examples are `states int8 [N,R,C]`, `policies f32 [N,A]`, `values f32 [N]`.  The 5 input
+planes are produced by the HIP encode kernel and the 8-fold symmetry augmentation runs batched on
+the device (the reference rebuilds a whole network per sample to encode it, data_utils.py:30-32).
+Training itself is stock PyTorch-ROCm (out of the hot path).
+"""
+import glob
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .network import YinYangNeuralNetwork
+
+
+def augment_batch(planes, policies):
+    """The reference's 8 variants, in its order (data_utils.py:52-132): identity, rot90 x1/x2/x3,
+    horizontal flip, vertical flip, transpose, anti-transpose -- applied to ALL 5 planes as images
+    (the reference does not swap the row-/column-fill planes under a rotation; neither do we) and to
+    the policy reshaped to the board.  planes [N,5,R,R], policies [N,R*R] -> [8N,...] with variant v
+    of sample n at row v*N + n.  Square boards only (the reference's code also only works there)."""
+    N, _, R, C = planes.shape
+    assert R == C, "augmentation needs a square board"
+    grid = policies.reshape(N, 1, R, C)
+
+    def both(fn):
+        return fn(planes), fn(grid).reshape(N, R * C)
+
+    outs = [
+        (planes, policies),
+        both(lambda t: torch.rot90(t, 1, (2, 3))),
+        both(lambda t: torch.rot90(t, 2, (2, 3))),
+        both(lambda t: torch.rot90(t, 3, (2, 3))),
+        both(lambda t: torch.flip(t, (3,))),
+        both(lambda t: torch.flip(t, (2,))),
+        both(lambda t: t.transpose(2, 3)),
+        both(lambda t: torch.flip(t.transpose(2, 3), (2, 3))),
+    ]
+    return torch.cat([o[0] for o in outs]).contiguous(), torch.cat([o[1] for o in outs]).contiguous()
+
+
+def load_examples(path):
+    """Read a self_play_data_*.npz written by generate_self_play_data (plain arrays, no pickles)."""
+    z = np.load(path, allow_pickle=False)
+    states = z["states"] if "states" in z.files else z["boards"]
+    return dict(states=torch.from_numpy(states.astype(np.int8)),
+                policies=torch.from_numpy(z["policies"].astype(np.float32)),
+                values=torch.from_numpy(z["values"].astype(np.float32)))
+
+
+class TrainingDataQueue:
+    """FIFO replay buffer (training_pipeline.py:23-106): newest `max_size` examples, uniform sampling
+    without replacement of `sample_size`."""
+
+    def __init__(self, max_size=500000, sample_size=10000):
+        self.max_size = max_size
+        self.sample_size = min(sample_size, max_size)
+        self.states = self.policies = self.values = None
+
+    def push_examples(self, examples):
+        if isinstance(examples, dict):
+            s, p, v = examples["states"].cpu(), examples["policies"].cpu().float(), examples["values"].cpu().float()
+        else:   # list of (board, policy, value) like the reference
+            s = torch.from_numpy(np.stack([np.asarray(e[0].get_board() if hasattr(e[0], "get_board") else e[0], np.int8) for e in examples]))
+            p = torch.from_numpy(np.stack([np.asarray(e[1], np.float32) for e in examples]))
+            v = torch.tensor([float(e[2]) for e in examples], dtype=torch.float32)
+        if self.states is None:
+            self.states, self.policies, self.values = s, p, v
+        else:
+            self.states = torch.cat([self.states, s])
+            self.policies = torch.cat([self.policies, p])
+            self.values = torch.cat([self.values, v])
+        if len(self) > self.max_size:
+            k = len(self) - self.max_size
+            self.states, self.policies, self.values = self.states[k:], self.policies[k:], self.values[k:]
+
+    def push_file(self, file_path):
+        if not os.path.exists(file_path):
+            return
+        self.push_examples(load_examples(file_path))
+
+    def sample(self, sample_size=None):
+        n = len(self)
+        if n == 0:
+            return {}
+        k = min(self.sample_size if sample_size is None else sample_size, n)
+        idx = torch.tensor(random.sample(range(n), k), dtype=torch.long)     # random.sample like :95
+        return dict(states=self.states[idx], policies=self.policies[idx], values=self.values[idx])
+
+    def __len__(self):
+        return 0 if self.states is None else int(self.states.shape[0])
+
+
+class AlphaZeroTrainer:
+    def __init__(self, game, model_dir="models", lr=0.001, batch_size=64, weight_decay=1e-4, device=None,
+                 num_channels=128, num_res_blocks=10):
+        self.game, self.model_dir, self.batch_size = game, model_dir, batch_size
+        os.makedirs(model_dir, exist_ok=True)
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.nnet = YinYangNeuralNetwork(game, num_channels, num_res_blocks).to(self.device)
+        self.optimizer = torch.optim.Adam(self.nnet.parameters(), lr=lr, weight_decay=weight_decay)
+
+    def _encode(self, states):
+        """int8 [N,R,C] -> planes f32 [N,5,R,C]: HIP encode kernel on a ROCm device, torch ops on CPU."""
+        if self.device.type == "cuda":
+            from . import engine
+            return engine.encode_planes(states.to(self.device).contiguous())
+        b = states.to(torch.int8)
+        occ = (b != 0)
+        n, m = b.shape[1:]
+        rows = (occ.sum(2).double() / m).float()[:, :, None].expand(-1, n, m)
+        cols = (occ.sum(1).double() / n).float()[:, None, :].expand(-1, n, m)
+        return torch.stack([(b == 0).float(), (b == 1).float(), (b == -1).float(), rows, cols], dim=1)
+
+    def train(self, examples, epochs=10, augment=True):
+        """trainer.py:67-161.  examples: dict of tensors (or the reference's list of tuples)."""
+        if not isinstance(examples, dict):
+            q = TrainingDataQueue(max_size=max(1, len(examples)))
+            q.push_examples(examples)
+            examples = dict(states=q.states, policies=q.policies, values=q.values)
+        planes = self._encode(examples["states"])
+        pol = examples["policies"].to(self.device).float()
+        val = examples["values"].to(self.device).float()
+        if augment:
+            planes, pol = augment_batch(planes, pol)
+            val = val.repeat(8)
+        n = planes.shape[0]
+        metrics = {"policy_loss": [], "value_loss": [], "total_loss": []}
+        self.nnet.train()
+        for _ in range(epochs):
+            perm = torch.randperm(n, device=self.device)
+            sums = torch.zeros(3, device=self.device)
+            for i in range(0, n, self.batch_size):
+                idx = perm[i:i + self.batch_size]
+                self.optimizer.zero_grad(set_to_none=True)
+                logits, v = self.nnet(planes[idx])
+                p_loss = F.cross_entropy(logits, pol[idx])               # soft targets, trainer.py:130
+                v_loss = F.mse_loss(v.reshape(-1), val[idx])             # :131
+                loss = p_loss + v_loss
+                loss.backward()
+                self.optimizer.step()
+                sums += torch.stack([p_loss.detach(), v_loss.detach(), loss.detach()]) * idx.numel()
+            pl, vl, tl = (sums / n).tolist()
+            metrics["policy_loss"].append(pl)
+            metrics["value_loss"].append(vl)
+            metrics["total_loss"].append(tl)
+        self.nnet.eval()
+        return metrics
+
+    def _path(self, filename, iteration):
+        if filename is None:
+            filename = f"checkpoint_{iteration}.pth.tar" if iteration is not None else "checkpoint.pth.tar"
+        return os.path.join(self.model_dir, filename)
+
+    def save_checkpoint(self, filename=None, iteration=None):
+        self.nnet.save_model(self._path(filename, iteration))
+
+    def load_checkpoint(self, filename=None, iteration=None):
+        path = self._path(filename, iteration)
+        if os.path.exists(path):
+            self.nnet.load_model(path)
+            self.nnet.to(self.device)
+
+    def predict(self, board):
+        return self.nnet.predict(board)
+
+
+class TrainingPipeline:
+    def __init__(self, game, model_dir="models", data_dir="data", lr=0.001, batch_size=64, weight_decay=1e-4,
+                 epochs_per_iteration=10, sample_size=10000, queue_size=500000, checkpoint_interval=10,
+                 device=None, num_channels=128, num_res_blocks=10):
+        self.game, self.model_dir, self.data_dir = game, model_dir, data_dir
+        self.epochs_per_iteration, self.sample_size, self.checkpoint_interval = epochs_per_iteration, sample_size, checkpoint_interval
+        for d in (model_dir, data_dir):
+            os.makedirs(d, exist_ok=True)
+        self.trainer = AlphaZeroTrainer(game, model_dir, lr, batch_size, weight_decay, device, num_channels, num_res_blocks)
+        self.data_queue = TrainingDataQueue(queue_size, sample_size)
+        self.iteration = 0
+        self._load_iteration()
+
+    def _load_iteration(self):          # training_pipeline.py:171-190: resume from the highest checkpoint_<n>
+        cps = glob.glob(os.path.join(self.model_dir, "checkpoint_*.pth.tar"))
+        its = [int(os.path.basename(c).split("_")[1].split(".")[0]) for c in cps]
+        if its:
+            self.iteration = max(its)
+            self.trainer.load_checkpoint(iteration=self.iteration)
+
+    def load_data(self):
+        for f in sorted(glob.glob(os.path.join(self.data_dir, "self_play_data_*.npz"))):
+            self.data_queue.push_file(f)
+
+    def train_iteration(self):
+        ex = self.data_queue.sample()
+        if not ex:
+            return {}
+        metrics = self.trainer.train(ex, epochs=self.epochs_per_iteration, augment=True)
+        self.iteration += 1
+        if self.iteration % self.checkpoint_interval == 0:
+            self.trainer.save_checkpoint(iteration=self.iteration)
+        return metrics
+
+    def train(self, num_iterations=10):
+        allm = {"policy_loss": [], "value_loss": [], "total_loss": []}
+        for _ in range(num_iterations):
+            m = self.train_iteration()
+            for k in allm:
+                allm[k].extend(m.get(k, []))
+        return allm
+
+    def get_latest_model_path(self):
+        name = f"checkpoint_{self.iteration}.pth.tar" if self.iteration > 0 else "checkpoint.pth.tar"
+        return os.path.join(self.model_dir, name)
+
+
+def run_training_pipeline(game, model_dir="models", data_dir="data", num_iterations=10, sample_size=10000,
+                          checkpoint_interval=10, **kw):
+    """training_pipeline.py:293-329: load every .npz in data_dir, train, return the latest checkpoint path."""
+    pipe = TrainingPipeline(game, model_dir, data_dir, sample_size=sample_size, checkpoint_interval=checkpoint_interval, **kw)
+    pipe.load_data()
+    t0 = time.perf_counter()
+    metrics = pipe.train(num_iterations)
+    run_training_pipeline.last = dict(metrics=metrics, seconds=time.perf_counter() - t0, examples=len(pipe.data_queue))
+    if not os.path.exists(pipe.get_latest_model_path()):
+        pipe.trainer.save_checkpoint(iteration=pipe.iteration if pipe.iteration > 0 else None)
+    return pipe.get_latest_model_path()
