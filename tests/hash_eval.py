@@ -39,3 +39,29 @@ def planes_to_boards(planes):
     """planes f32[G,5,R,C] (board_to_input layout) -> int8[G,R,C]."""
     p = np.asarray(planes)
     return (p[:, 1] - p[:, 2]).astype(np.int8)
+
+
+def hash_eval_torch(planes, pbits, vbits):
+    """The same hash evaluator as torch int64 ops on the device: planes f32 [G,5,R,C] -> (policy, value).
+    Lets full-size batches (G = 4096) be searched without a host round trip per simulation."""
+    import torch
+    G = planes.shape[0]
+    b = (planes[:, 1] - planes[:, 2]).to(torch.int64).reshape(G, -1)
+    A = b.shape[1]
+    M = 0xFFFFFFFF
+    code = b & 3
+    h = torch.full((G,), 0x9E3779B9, dtype=torch.int64, device=planes.device)
+    for i in range(A):
+        h = (((h ^ code[:, i]) * 16777619) + i) & M
+    a = torch.arange(A, dtype=torch.int64, device=planes.device)[None, :]
+    x = (h[:, None] + a * 0x9E3779B1) & M
+    x = x ^ (x >> 15)
+    x = (x * 0x2C1B3C6D) & M
+    x = x ^ (x >> 12)
+    pol = (1 + (x & ((1 << pbits) - 1))).to(torch.float32) / float(1 << (pbits + 6))
+    y = h ^ (h >> 16)
+    y = (y * 0x045D9F3B) & M
+    y = y ^ (y >> 13)
+    half = 1 << (vbits - 1)
+    val = ((y & ((1 << vbits) - 1)) - half).to(torch.float32) / float(half)
+    return pol.contiguous(), val.contiguous()

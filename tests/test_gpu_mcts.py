@@ -205,3 +205,53 @@ def test_arena_overflow_is_a_status(pkg):
         m.status()
     assert ei.value.code == -6
     m.close()
+
+
+@pytest.mark.parametrize("copied", [1, 0], ids=["copied", "aliased"])
+def test_full_size_batch_4096_games(pkg, copied):
+    """BASELINE config[1] batch size: G = 4096 concurrent 8x8 games searched together (device-side hash
+    evaluator, fused step kernel), a random subset checked bit-for-bit against the CPU oracle, plus
+    size-independent invariants on all games: root.visits == sims, sum(counts) == sims for non-terminal
+    roots, pi sums to 1, counts only on legal moves, boards unchanged in copied mode."""
+    import torch
+    from hash_eval import hash_eval_torch
+    G, R, C, sims = 4096, 8, 8, 96
+    rng = np.random.default_rng(77 + copied)
+    # staggered positions: random legal play for (g mod 40) plies, generated with the HIP rules kernels
+    E = pkg.engine
+    boards = torch.zeros((G, R, C), dtype=torch.int8, device="cuda")
+    players = torch.ones(G, dtype=torch.int8, device="cuda")
+    target = torch.arange(G, device="cuda") % 40
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    for ply in range(40):
+        mask = E.valid_mask(boards, players).float()
+        adv = (ply < target) & (mask.sum(1) > 0)
+        act = torch.multinomial(torch.where(adv[:, None], mask, torch.ones_like(mask)), 1, generator=gen).reshape(-1).to(torch.int32)
+        act = torch.where(adv, act, torch.full_like(act, -1)).contiguous()
+        old = players.clone()
+        E.step_(boards, players, act)
+        players = torch.where(adv, players, old).contiguous()
+    b0 = boards.clone()
+    m = E.BatchedMCTS(G, R, C, sims, aliased=not copied)
+    counts = m.search(boards, players, lambda p: hash_eval_torch(p, 6, 4), sims)
+    pi = m.root_policy()
+    visits, _ = m.root_stats()
+    fb = m.boards()
+    ctr = m.status()
+    c, pi_h = counts.cpu().numpy(), pi.cpu().numpy()
+    legal = E.valid_mask(b0, players).cpu().numpy()
+    ended = E.game_ended(b0, players).cpu().numpy()
+    assert (visits.cpu().numpy() == sims).all()
+    assert ((c.sum(1) == sims) | (legal.sum(1) == 0) | (ended != 0)).all()
+    assert np.allclose(pi_h.sum(1), 1.0)
+    assert ((c > 0) <= (legal > 0)).all()
+    if copied:
+        assert torch.equal(fb, b0)
+    assert ctr["evals"] <= G * sims and ctr["nodes"] <= ctr["evals"]
+    bh, ph = b0.cpu().numpy(), players.cpu().numpy()
+    for g in rng.choice(G, size=48, replace=False):
+        r = O.search_hash(bh[g], int(ph[g]), sims, copied, 6, 4)
+        assert np.array_equal(c[g], r.counts), g
+        assert np.array_equal(fb[g].cpu().numpy(), r.final_board), g
+    m.close()
