@@ -70,6 +70,47 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// Wave64 reductions on the VALU with DPP (row_shr 1/2/4/8 scan inside each 16-lane row, then row_bcast15 /
+// row_bcast31 across rows; lane 63 ends up with the total): ~6 dependent VALU ops instead of 6 LDS-crossbar
+// shuffles.  Used on the latency-critical PUCT descent.
+#define YY_DPP_STEP(OP, ID, v, ctrl, rmask) \
+    v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)(ID), (int)(v), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    YY_DPP_STEP(umax32, 0u, v, 0x111, 0xf);
+    YY_DPP_STEP(umax32, 0u, v, 0x112, 0xf);
+    YY_DPP_STEP(umax32, 0u, v, 0x114, 0xf);
+    YY_DPP_STEP(umax32, 0u, v, 0x118, 0xf);
+    YY_DPP_STEP(umax32, 0u, v, 0x142, 0xa);
+    YY_DPP_STEP(umax32, 0u, v, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x111, 0xf);
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x112, 0xf);
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x114, 0xf);
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x118, 0xf);
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x142, 0xa);
+    YY_DPP_STEP(umin32, 0xFFFFFFFFu, v, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_uadd(uint32_t v) {
+    YY_DPP_STEP(uadd32, 0u, v, 0x111, 0xf);
+    YY_DPP_STEP(uadd32, 0u, v, 0x112, 0xf);
+    YY_DPP_STEP(uadd32, 0u, v, 0x114, 0xf);
+    YY_DPP_STEP(uadd32, 0u, v, 0x118, 0xf);
+    YY_DPP_STEP(uadd32, 0u, v, 0x142, 0xa);
+    YY_DPP_STEP(uadd32, 0u, v, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// float -> unsigned key with the same order (all non-NaN keys are > 0)
+__device__ __forceinline__ uint32_t f32_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 template <int NW> __device__ __forceinline__ BB<NW> bb_uniform_load(const uint64_t *p) {
     BB<NW> r;
 #pragma unroll
@@ -564,6 +605,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
     int32_t *path = d.path + (size_t)g * d.path_cap;
 
     int node = 0, depth = 0, parent = -1, action = -1, kind;
+    int s_carry = rfl(st->root_N);
     uint64_t c_levels = 0, c_scan = 0;
     for (;;) {
         const uint4 hdr = nodes[node];
@@ -573,14 +615,20 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         if (k == 0) { kind = (node == 0) ? K_ROOTPASS : K_REEXPAND; break; }      // mcts.py:93-95
         if (depth >= (int)d.path_cap) { kind = K_NONE; if (lane == 0) st->err = 1; break; }
         // ---- Node.select_child (mcts.py:97-145), float32 order of SURVEY 8a/a12
-        int S = 0;
-        float bu = -INFINITY;
-        int bi = 0x7FFFFFFF;
-        uint32_t bw = 0;
-        // pass 1: sum of child visits (mcts.py:112)
-        for (int j = lane; j < k; j += 64) S += (int)edges[first + j].y;
-        S = wave_sum(S);
+        // sum of child visits (mcts.py:112).  Copied boards: every visit of an expanded node after its
+        // first descends into exactly one child, so the sum is N(node)-1 (root: completed simulations) and
+        // is carried down the descent; aliased boards can give a pass node children later, so sum there.
+        int S;
+        if (d.aliased) {
+            uint32_t part = 0;
+            for (int j = lane; j < k; j += 64) part += edges[first + j].y;
+            S = (int)wave_uadd(part);
+        } else {
+            S = s_carry;
+        }
         const float sq = d.sqrt_tab[min(S, d.sqrt_n - 1)];   // f32(math.sqrt(sum_visits))
+        uint32_t bk = 0, bw = 0, bn = 0;
+        int bi = 0x7FFFFFFF;
         for (int j = lane; j < k; j += 64) {
             const uint4 e = edges[first + j];
             const float P = __uint_as_float(e.x), W = __uint_as_float(e.z);
@@ -589,19 +637,24 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             const float t2 = __fmul_rn(t1, sq);
             const float u = __fdiv_rn(t2, (float)(1 + N));
             const float q = (N > 0) ? __fdiv_rn(W, (float)N) : 0.0f;
-            const float ucb = __fadd_rn(q, u);
-            if (ucb > bu) { bu = ucb; bi = j; bw = e.w; }                          // strict >, mcts.py:133
+            const float ucb = __fadd_rn(__fadd_rn(q, u), 0.0f);   // + 0.0f: -0.0 compares equal to +0.0 (mcts.py:133)
+            const uint32_t key = f32_key(ucb);
+            if (key > bk) { bk = key; bi = j; bw = e.w; bn = e.y; }               // strict >: lowest j of a lane
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ou = __shfl_xor(bu, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            const uint32_t ow = __shfl_xor(bw, o, 64);
-            if (ou > bu || (ou == bu && oi < bi)) { bu = ou; bi = oi; bw = ow; }   // lowest index wins ties
+        const uint32_t mx = wave_umax(bk);
+        const bool tied = (bk == mx) && (bi != 0x7FFFFFFF);
+        int best;
+        if (k <= 64) {   // lane == child index: lowest tied lane = lowest action (mcts.py:133)
+            const uint64_t tm = __ballot(tied);
+            best = tm ? (int)__ffsll((unsigned long long)tm) - 1 : 0x7FFFFFFF;
+        } else {
+            const uint32_t mi = wave_umin(tied ? (uint32_t)bi : 0xFFFFFFFFu);
+            best = (mx == 0u || mi == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)mi;
         }
-        const int best = rfl(bi);
-        const uint32_t w = rfl(bw);
+        if (mx == 0u) best = 0x7FFFFFFF;
         if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = 1; break; }  // NaN priors
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)bw, best & 63);
+        s_carry = (int)__builtin_amdgcn_readlane((int)bn, best & 63) - 1;
         if (lane == 0) path[depth] = first + best;
         depth++;
         c_levels++;
