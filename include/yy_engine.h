@@ -190,6 +190,12 @@ int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float
                            void *out_heads, int G, int R, int C, int channels, int n_layers,
                            yy_stream_t stream);
 
+/* Head finish (neural_network.py:115, 120-121, 152): h bf16 [G, A+H] = policy logits then value_fc1
+ * outputs (bias added); policy float32 [G,A] = softmax(logits); value float32 [G] =
+ * tanh(relu(hidden) . w2 + b2) with w2 float32 [H], b2 float32 [1]. */
+int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2,
+                           float *policy, float *value, yy_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,5 +112,12 @@ def test_tower_kernel_matches_torch_bf16_path():
         vf = tow._conv(xt, tow.vhead, 0).contiguous().flatten(1).float()
         fs = max(float(pf.abs().max()), float(vf.abs().max()))
         assert float((feats[:, 0] - pf).abs().max()) <= fs * 2.0 ** -7 and float((feats[:, 1] - vf).abs().max()) <= fs * 2.0 ** -7
+        # head finish kernel against torch ops on the same GEMM output
+        hc = torch.nn.functional.linear(pkg.engine.tower_heads_forward(planes, towh.towerh_w, towh.towerh_b, towh.tower_layers).view(G, -1),
+                                        towh.fc_cat_w, towh.fc_cat_b)
+        pk, vk = pkg.engine.head_finish(hc, 64, towh.fc2_w, towh.fc2_b)
+        pt = torch.softmax(hc[:, :64].float(), 1)
+        vt = torch.tanh(torch.relu(hc[:, 64:].float()) @ towh.fc2_w + towh.fc2_b)
+        assert float((pk - pt).abs().max()) < 1e-6 and float((vk - vt).abs().max()) < 1e-5
         p_h, v_h = towh(planes)
         assert float((p_h - p_t).abs().max()) < 2e-2 and float((v_h - v_t).abs().max()) < 5e-2

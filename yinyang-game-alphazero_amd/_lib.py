@@ -72,6 +72,7 @@ _SIGS = {
     "yy_nn_bias_act_bf16": [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp],
     "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_head_finish_bf16": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     "yy_version": [],
 }
 

@@ -1204,3 +1204,36 @@ extern "C" int yy_nn_bias_act_bf16(void *x, const float *bias, const void *resid
     HIP_TRY(hipGetLastError());
     return YY_OK;
 }
+
+// Head finish (neural_network.py:115, 120-121 + predict's softmax :152): row g of h holds the A policy logits
+// followed by the H hidden activations of value_fc1 (bias already added by the GEMM, bf16).  One wave per
+// row: policy = softmax(logits) in f32; value = tanh(sum_j relu(hidden_j) * w2_j + b2).
+__global__ void __launch_bounds__(64) k_head_finish(const unsigned short *__restrict__ h, int A, int H,
+                                                    const float *__restrict__ w2, const float *__restrict__ b2,
+                                                    float *__restrict__ policy, float *__restrict__ value) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const unsigned short *row = h + (size_t)g * (A + H);
+    float mx = -INFINITY;
+    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, bf2f(row[a]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int a = lane; a < A; a += 64) sum += expf(bf2f(row[a]) - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int a = lane; a < A; a += 64) policy[(size_t)g * A + a] = expf(bf2f(row[a]) - mx) / sum;
+    float acc = 0.0f;
+    for (int j = lane; j < H; j += 64) acc += fmaxf(bf2f(row[A + j]), 0.0f) * w2[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) value[g] = tanhf(acc + b2[0]);
+}
+
+extern "C" int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2, float *policy,
+                                      float *value, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (!h || !w2 || !b2 || !policy || !value || G < 0 || A <= 0 || H <= 0) return set_err(YY_E_INVALID, "bad argument%s%s");
+    k_head_finish<<<dim3(G), dim3(64), 0, (hipStream_t)s>>>((const unsigned short *)h, A, H, w2, b2, policy, value);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}

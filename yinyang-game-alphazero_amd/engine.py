@@ -164,6 +164,20 @@ def tower_heads_forward(planes, weights, bias, n_layers):
     return out
 
 
+def head_finish(h, A, w2, b2):
+    """softmax over the first A columns of h (bf16 [G, A+H]) and tanh(relu(h[:, A:]) @ w2 + b2) in one
+    HIP pass (csrc k_head_finish) -> (policy f32 [G,A], value f32 [G])."""
+    G, W = h.shape
+    _need(h, torch.bfloat16, name="h")
+    _need(w2, torch.float32, (W - A,), "w2")
+    _need(b2, torch.float32, (1,), "b2")
+    policy = torch.empty((G, A), dtype=torch.float32, device=h.device)
+    value = torch.empty(G, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        check(lib().yy_nn_head_finish_bf16(_p(h), G, A, W - A, _p(w2), _p(b2), _p(policy), _p(value), _stream()))
+    return policy, value
+
+
 # ------------------------------------------------------------------ batched MCTS context
 class BatchedMCTS:
     """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate

@@ -199,6 +199,17 @@ class BatchedEvaluator:
                 hw, hb = pack_heads(net)
                 self.towerh_w = torch.cat([wq, hw]).contiguous().to(self.device)
                 self.towerh_b = torch.cat([bq, hb]).contiguous().to(self.device)
+                # policy_fc and value_fc1 as ONE GEMM over [policy features | value features] (block weights)
+                A, F_ = net.policy_fc.out_features, net.policy_fc.in_features
+                Hd = net.value_fc1.out_features
+                wc = torch.zeros((A + Hd, 2 * F_), dtype=torch.float32, device=self.device)
+                wc[:A, :F_] = net.policy_fc.weight.detach()
+                wc[A:, F_:] = net.value_fc1.weight.detach()
+                self.fc_cat_w = wc.to(self.dtype).contiguous()
+                self.fc_cat_b = torch.cat([net.policy_fc.bias.detach(), net.value_fc1.bias.detach()]).to(self.dtype).contiguous()
+                self.fc2_w = net.value_fc2.weight.detach().float().reshape(-1).contiguous()
+                self.fc2_b = net.value_fc2.bias.detach().float().reshape(1).contiguous()
+                self.n_actions = A
 
     def _fold(self):
         n, dt = self.net, self.dtype
@@ -233,10 +244,8 @@ class BatchedEvaluator:
         if self.tower and self.fused_heads:
             from . import engine
             feats = engine.tower_heads_forward(planes, self.towerh_w, self.towerh_b, self.tower_layers)
-            logits = F.linear(feats[:, 0], *self.pfc).float()
-            hdn = F.relu(F.linear(feats[:, 1], *self.vfc1)).float()
-            value = torch.tanh(F.linear(hdn, *self.vfc2)).reshape(-1)
-            return F.softmax(logits, dim=1), value
+            hcat = F.linear(feats.view(feats.shape[0], -1), self.fc_cat_w, self.fc_cat_b)    # [G, A + 256] bf16
+            return engine.head_finish(hcat, self.n_actions, self.fc2_w, self.fc2_b)
         if self.tower:
             from . import engine
             x = engine.tower_forward(planes, self.tower_w, self.tower_b, self.tower_layers)
