@@ -181,10 +181,6 @@ int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_
 int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G,
                      int R, int C, int channels, int n_layers, yy_stream_t stream);
 
-/* Fragment geometry the tower kernel expects its weights in: 32 (v_mfma_f32_32x32x16_bf16: chunk
- * [ks 4][nt 4][h 2][c 32][j 8]) or 16 (v_mfma_f32_16x16x32_bf16: chunk [ks 2][rt 8][g 4][r 16][j 8]). */
-int yy_nn_tower_mfma_shape(void);
-
 /* Same kernel, with the policy_conv / value_conv 1x1 head convolutions + BatchNorm + ReLU
  * (neural_network.py:113, 118) fused behind the tower: out_heads bf16 [G,2,32,64] = [policy features,
  * value features] in the reference's NCHW flatten order (channel*64 + cell, :114 / :119), ready for

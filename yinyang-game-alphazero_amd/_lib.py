@@ -32,12 +32,12 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_tower16.hip"),
+    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"),
             os.path.join(CSRC, "yy_bitboard.h"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, srcs[0], srcs[1], srcs[2]]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO, srcs[0], srcs[1]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -73,7 +73,6 @@ _SIGS = {
     "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_head_finish_bf16": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
-    "yy_nn_tower_mfma_shape": [],
     "yy_version": [],
 }
 

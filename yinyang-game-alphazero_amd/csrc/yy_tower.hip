@@ -341,16 +341,6 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
 
 // weights: bf16 chunks [9 + 18*(n_layers-1) (+1 head chunk)][8192] in fragment order (network.pack_tower);
 // bias f32 [n_layers (+1)][128]; planes f32 [G,5,8,8]; out bf16 [G,8,8,128] or out_heads bf16 [G,2,32,64].
-extern "C" int yy_tower16_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
-                                 int G, int n_layers, yy_stream_t s);   // yy_tower16.hip
-
-// MFMA shape the tower kernel is built around: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16.  The
-// host packs the weights in the matching fragment order (network.pack_tower asks this function).
-extern "C" int yy_nn_tower_mfma_shape(void) {
-    static const int shape = getenv("YY_TOWER_SHAPE") ? atoi(getenv("YY_TOWER_SHAPE")) : 32;
-    return shape == 16 ? 16 : 32;
-}
-
 static int launch_tower(const float *planes, const void *weights, const float *bias, void *out, void *out_heads, int G,
                         int R, int C, int channels, int n_layers, yy_stream_t s) {
     if (G == 0) return YY_OK;
@@ -359,7 +349,6 @@ static int launch_tower(const float *planes, const void *weights, const float *b
     if (R != 8 || C != 8 || channels != TW_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > TW_MAX_LAYERS || (n_layers & 1) == 0)
         return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 8x8 boards, 128 channels, at most 10 residual blocks");
     static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
-    if (yy_nn_tower_mfma_shape() == 16) return yy_tower16_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
     const unsigned char *w = (const unsigned char *)weights;
     unsigned short *o = (unsigned short *)out, *oh = (unsigned short *)out_heads;

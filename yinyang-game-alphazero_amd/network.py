@@ -132,8 +132,6 @@ def pack_tower(net):
     cout = ntile*32 + c, cin = half*64 + ks*16 + h*8 + j; layer 0 (stem) has 9 chunks (one per tap,
     5 input planes zero-padded to 16 channels), every other layer 18 (tap-major, then half);
     bias float32 [n_layers, 128]."""
-    from ._lib import lib
-    shape = lib().yy_nn_tower_mfma_shape()
     convs = [(net.conv1, net.bn1)]
     for blk in net.res_blocks:
         convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
@@ -147,10 +145,8 @@ def pack_tower(net):
         wp[:, :cin] = w
         for tap in range(9):
             wt = wp[:, :, tap // 3, tap % 3]                  # [cout, cin]
-            if shape == 16:   # v_mfma_f32_16x16x32_bf16: [half][ks 2][rt 8][g 4][r 16][j 8]
-                t = wt.reshape(8, 16, 2, 2, 4, 8).permute(2, 3, 0, 4, 1, 5).contiguous()
-            else:             # v_mfma_f32_32x32x16_bf16: [half][ks 4][nt 4][h 2][c 32][j 8]
-                t = wt.reshape(4, 32, 2, 4, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous()
+            t = wt.reshape(4, 32, 2, 4, 2, 8)                 # nt, c, half, ks, h, j
+            t = t.permute(2, 3, 0, 4, 1, 5).contiguous()      # half, ks, nt, h, c, j
             for half in range(1 if li == 0 else 2):
                 chunks.append(t[half].reshape(-1))
         biases.append(b.float().cpu())
@@ -164,13 +160,8 @@ def pack_heads(net):
     and one extra bias row [policy 32 | value 32 | zeros]."""
     wp, bp = fold_batchnorm(net.policy_conv, net.policy_bn)      # [32,128,1,1]
     wv, bv = fold_batchnorm(net.value_conv, net.value_bn)
-    from ._lib import lib
-    if lib().yy_nn_tower_mfma_shape() == 16:
-        w = torch.cat([wp, wv]).float().cpu().reshape(4, 16, 4, 4, 8)   # rt, r, ks, g, j
-        chunk = w.permute(2, 0, 3, 1, 4).contiguous().reshape(1, -1)    # ks, rt, g, r, j
-    else:
-        w = torch.cat([wp, wv]).float().cpu().reshape(2, 32, 8, 2, 8)   # nt, c, ks, h, j
-        chunk = w.permute(2, 0, 3, 1, 4).contiguous().reshape(1, -1)    # ks, nt, h, c, j
+    w = torch.cat([wp, wv]).float().cpu().reshape(2, 32, 8, 2, 8)   # nt, c, ks, h, j
+    chunk = w.permute(2, 0, 3, 1, 4).contiguous().reshape(1, -1)    # ks, nt, h, c, j
     bias = torch.zeros(1, 128)
     bias[0, :32], bias[0, 32:64] = bp.float().cpu(), bv.float().cpu()
     return chunk.to(torch.bfloat16).view(torch.int16).contiguous(), bias
