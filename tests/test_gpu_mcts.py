@@ -255,3 +255,29 @@ def test_full_size_batch_4096_games(pkg, copied):
         assert np.array_equal(c[g], r.counts), g
         assert np.array_equal(fb[g].cpu().numpy(), r.final_board), g
     m.close()
+
+
+def test_search_with_rowcol_rule_vs_oracle(pkg):
+    """YY_FLAG_ROWCOL inside the tree kernels (browser-only rule; pinned by the oracle only)."""
+    import torch
+    R, C, sims, G = 5, 5, 80, 24
+    rng = np.random.default_rng(31)
+    boards = np.zeros((G, R, C), np.int8)
+    pl = np.ones(G, np.int8)
+    for ply in range(14):
+        m = O.valid_mask(boards, pl, flags=1)
+        go = (rng.random(G) < 0.9) & m.any(1)
+        act = np.array([rng.choice(np.flatnonzero(r)) if r.any() else 0 for r in m], np.int32)
+        nb, npl, _ = O.next_state(boards, pl, act, flags=1)
+        boards[go], pl[go] = nb[go], npl[go]
+    for copied in (1, 0):
+        m = pkg.engine.BatchedMCTS(G, R, C, sims, aliased=not copied, rowcol=True)
+        ev = HostHashEvaluator([6] * G, [4] * G, m.needs_eval)
+        counts = m.search(torch.from_numpy(boards).cuda(), torch.from_numpy(pl).cuda(), ev, sims).cpu().numpy()
+        fb = m.boards().cpu().numpy()
+        m.status()
+        for g in range(G):
+            r = O.search_hash(boards[g], int(pl[g]), sims, copied, 6, 4, flags=1)
+            assert np.array_equal(counts[g], r.counts), (copied, g)
+            assert np.array_equal(fb[g], r.final_board), (copied, g)
+        m.close()

@@ -194,13 +194,12 @@ class BatchedMCTS:
         self.max_sims, self.cpuct, self.aliased, self.rowcol = int(max_sims), float(cpuct), bool(aliased), bool(rowcol)
         cfg = MctsConfig(self.G, self.R, self.C, self.max_sims, self.cpuct, _flags(rowcol, aliased),
                          int(edges_per_game), int(nodes_per_game))
-        h = C_void_p()
+        h = ct.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().yy_mcts_create(ct.byref(cfg), ct.byref(h)))
         self._h = h
         self.planes = torch.zeros((self.G, 5, self.R, self.C), dtype=torch.float32, device=self.device)
         self.needs_eval = torch.zeros(self.G, dtype=torch.uint8, device=self.device)
-        self._keep = []   # tensors referenced by enqueued kernels
 
     # -- lifetime
     def close(self):
@@ -311,7 +310,3 @@ class BatchedMCTS:
                 if s + 1 < num_sims:
                     self.select()
         return self.root_counts()
-
-
-def C_void_p():
-    return ct.c_void_p()
