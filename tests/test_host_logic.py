@@ -135,3 +135,14 @@ def test_gather_examples_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_shard_games_partitions_every_world_size():
+    from yinyang_game_alphazero_amd.self_play import shard_games
+    for total in (0, 1, 7, 8, 100, 4096, 4099):
+        for world in (1, 2, 3, 4, 8):
+            ids = []
+            for r in range(world):
+                n, first, stride = shard_games(total, r, world)
+                ids += [first + i * stride for i in range(n)]
+            assert sorted(ids) == list(range(total)), (total, world)

@@ -261,7 +261,16 @@ class SelfPlayEngine:
         self.ctx.close()
 
 
-# =============================================================================== multi-GPU gather
+# =============================================================================== multi-GPU sharding + gather
+def shard_games(total, rank, world):
+    """Episode sharding (replaces `games_per_worker` processes, self_play.py:299-304): rank r of `world` plays the
+    games with global index r, r + world, r + 2*world, ... < total.  Returns (count, first_index, stride); the
+    union over ranks is exactly range(total) for any world size, so per-game ids do not depend on it."""
+    count = total // world + (1 if rank < total % world else 0)
+    return count, rank, world
+
+
+
 def gather_examples(ex, group=None):
     """One exchange at iteration end: all_gather of the example counts, then all_gather of the padded
     (state, pi, z) tensors (RCCL over xGMI on GPUs; gloo on CPU tensors in the tests).  Equivalent of
@@ -397,7 +406,7 @@ class SelfPlayManager:
         import torch.distributed as dist
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
         total = self.num_workers * self.games_per_worker
-        mine = total // world + (1 if rank < total % world else 0)
+        mine, first, stride = shard_games(total, rank, world)
         dev = torch.device("cuda", torch.cuda.current_device())
         net = YinYangNeuralNetwork(self.game, self.num_channels, self.num_res_blocks)
         if os.path.exists(self.model_path):
@@ -408,7 +417,7 @@ class SelfPlayManager:
                              dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                              temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
                              reference_quirks=self.reference_quirks, seed=self.seed * 1000003 + rank,
-                             first_game_index=rank, game_index_stride=world, device=dev)
+                             first_game_index=first, game_index_stride=stride, device=dev)
         t0 = time.perf_counter()
         ex = eng.run(mine) if mine > 0 else eng.collect()
         torch.cuda.synchronize(dev)
