@@ -61,3 +61,33 @@ def test_alphazero_player_api():
     full = game.getInitBoard()
     full.board[...] = np.array([[1, -1, 1, -1], [-1, 1, -1, 1], [1, -1, 1, -1], [-1, 1, -1, 1]], np.int8)
     assert rp.play(full, 1) == -1
+
+
+def test_cli_self_play_config1(tmp_path):
+    """BASELINE config[0] plumbing: `train_alphazero.py --mode self-play --rows 6 --cols 6 --simulations 25
+    --episodes 4 --workers 1` (train_alphazero.py:103-122): refuses to run without the model file, writes
+    data/self_play_data_<ts>.npz with boards/policies/values of matching length."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir, ddir = tmp_path / "models", tmp_path / "data"
+    cmd = [sys.executable, os.path.join(root, "train_alphazero.py"), "--mode", "self-play", "--rows", "6", "--cols", "6",
+           "--simulations", "25", "--episodes", "4", "--workers", "1", "--model-dir", str(mdir), "--data-dir", str(ddir),
+           "--nn", "fp32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "Model file not found" in (r.stderr + r.stdout)
+    torch.manual_seed(0)
+    pkg.YinYangNeuralNetwork(pkg.YinYangGame(6, 6)).save_model(str(mdir / "best_model.pth.tar"))
+    for extra, lo, hi in (([], 40, 37 * 4), (["--board-semantics", "aliased", "--reference-quirks"], 4, 60)):
+        r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        z = np.load(info["data_file"])
+        n = z["boards"].shape[0]
+        assert z["boards"].shape == (n, 6, 6) and z["policies"].shape == (n, 36) and z["values"].shape == (n,)
+        assert lo <= n <= hi and len(np.unique(z["game_id"])) == 4
+        assert np.allclose(z["policies"].sum(1), 1.0, atol=1e-6)
+        os.remove(info["data_file"])
