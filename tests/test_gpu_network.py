@@ -121,3 +121,50 @@ def test_tower_kernel_matches_torch_bf16_path():
         assert float((pk - pt).abs().max()) < 1e-6 and float((vk - vt).abs().max()) < 1e-5
         p_h, v_h = towh(planes)
         assert float((p_h - p_t).abs().max()) < 2e-2 and float((v_h - v_t).abs().max()) < 5e-2
+
+
+def test_tower12_kernel_matches_torch_bf16_path():
+    """12x12 variant (csrc/yy_tower12.hip): same checks as the 8x8 kernel -- tower activations within 2 bf16 ulps of
+    scale per layer against torch bf16 convolutions on the same folded weights, fused head features within 2 ulps,
+    end-to-end policy 2e-2 / value 5e-2 abs against the torch bf16 path and the fp32 module."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(1)
+    game = pkg.YinYangGame(12, 12)
+    rng = np.random.default_rng(4)
+    for blocks, G in ((1, 5), (10, 67)):
+        net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.1)
+                if isinstance(m, torch.nn.Conv2d):
+                    m.bias.normal_(0, 0.05)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 12, 12)).astype(np.int8)).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        ref = pkg.BatchedEvaluator(net, "bf16", tower=False)
+        tow = pkg.BatchedEvaluator(net, "bf16", tower=True, fused_heads=False)
+        towh = pkg.BatchedEvaluator(net, "bf16", tower=True, fused_heads=True)
+        assert tow.tower and towh.fused_heads and not ref.tower
+        x_t = pkg.engine.tower_forward(planes, tow.tower_w, tow.tower_b, tow.tower_layers)
+        x = planes.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x = ref._conv(x, ref.stem, 1)
+        for (c1, c2) in ref.blocks:
+            y = ref._conv(x, c1, 1)
+            x = ref._conv(y, c2, 1, residual=x)
+        scale = float(x.float().abs().max())
+        assert float((x_t.float() - x.float()).abs().max()) <= scale * 2.0 ** -7 * (1 + blocks)
+        feats = pkg.engine.tower_heads_forward(planes, towh.towerh_w, towh.towerh_b, towh.tower_layers).float()
+        pf = tow._conv(x_t, tow.phead, 0).contiguous().flatten(1).float()
+        vf = tow._conv(x_t, tow.vhead, 0).contiguous().flatten(1).float()
+        fs = max(float(pf.abs().max()), float(vf.abs().max()))
+        assert float((feats[:, 0] - pf).abs().max()) <= fs * 2.0 ** -7 and float((feats[:, 1] - vf).abs().max()) <= fs * 2.0 ** -7
+        p_r, v_r = ref(planes)
+        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+        for ev in (tow, towh):
+            p, v = ev(planes)
+            assert p.shape == (G, 144) and float((p - p_r).abs().max()) < 2e-2 and float((v - v_r).abs().max()) < 5e-2
+            assert float((p - p32).abs().max()) < 2e-2 and float((v - v32).abs().max()) < 5e-2

@@ -137,30 +137,30 @@ def bias_act_(x, bias, residual=None, relu=True):
 
 
 def tower_forward(planes, weights, bias, n_layers):
-    """Stem + residual tower in one LDS-resident MFMA kernel (csrc/yy_tower.hip).
-    planes f32 [G,5,8,8] -> bf16 activations as a channels-last tensor [G,128,8,8]."""
-    G = planes.shape[0]
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    """Stem + residual tower in one LDS-resident MFMA kernel (csrc/yy_tower.hip, yy_tower12.hip).
+    planes f32 [G,5,R,R] (R = 8 or 12) -> bf16 activations as a channels-last tensor [G,128,R,R]."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     n_chunks = 9 + 18 * (n_layers - 1)
     _need(weights, torch.int16, (n_chunks, 8192), "tower weights")
     _need(bias, torch.float32, (n_layers, 128), "tower bias")
-    out = torch.empty((G, 8, 8, 128), dtype=torch.bfloat16, device=planes.device)
+    out = torch.empty((G, R, Cc, 128), dtype=torch.bfloat16, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_bf16(_p(planes), _p(weights), _p(bias), _p(out), G, 8, 8, 128, n_layers, _stream()))
+        check(lib().yy_nn_tower_bf16(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, _stream()))
     return out.permute(0, 3, 1, 2)      # NCHW view of NHWC memory == channels_last
 
 
 def tower_heads_forward(planes, weights, bias, n_layers):
-    """Tower + fused 1x1 head convolutions (csrc/yy_tower.hip): planes f32 [G,5,8,8] ->
-    bf16 [G,2,2048] = (policy features, value features) in the reference's flatten order."""
-    G = planes.shape[0]
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    """Tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] (R = 8 or 12) ->
+    bf16 [G,2,32*R*R] = (policy features, value features) in the reference's flatten order."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     n_chunks = 9 + 18 * (n_layers - 1) + 1
     _need(weights, torch.int16, (n_chunks, 8192), "tower+heads weights")
     _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
-    out = torch.empty((G, 2, 2048), dtype=torch.bfloat16, device=planes.device)
+    out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.bfloat16, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_heads_bf16(_p(planes), _p(weights), _p(bias), _p(out), G, 8, 8, 128, n_layers, _stream()))
+        check(lib().yy_nn_tower_heads_bf16(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, _stream()))
     return out
 
 
