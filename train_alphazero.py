@@ -68,7 +68,8 @@ def main(argv=None):
         az = pkg.AlphaZero(game, args.model_dir, args.data_dir, num_iterations=args.iterations, num_episodes=args.episodes,
                            num_simulations=args.simulations, num_epochs=args.epochs, num_workers=args.workers,
                            mcts_threads=args.mcts_threads, nn_mode=args.nn, concurrent_games=args.concurrent_games,
-                           arena_games=args.arena_games, num_channels=args.channels, num_res_blocks=args.blocks)
+                           arena_games=args.arena_games, num_channels=args.channels, num_res_blocks=args.blocks,
+                           lr=args.lr, batch_size=args.batch_size)
         hist = az.run()
         if rank == 0:
             print(json.dumps({"iterations": hist}))

@@ -178,22 +178,28 @@ class AlphaZero:
     def __init__(self, game, model_dir="models", data_dir="data", num_iterations=100, num_episodes=100,
                  num_simulations=800, num_epochs=10, temperature_threshold=10, update_threshold=0.6, num_workers=1,
                  mcts_threads=1, arena_games=40, nn_mode="bf16", num_channels=128, num_res_blocks=10,
-                 concurrent_games=4096, device=None):
+                 concurrent_games=4096, device=None, lr=0.001, batch_size=64):
         self.game, self.model_dir, self.data_dir = game, model_dir, data_dir
         self.num_iterations, self.num_episodes, self.num_simulations = num_iterations, num_episodes, num_simulations
         self.num_epochs, self.temperature_threshold, self.update_threshold = num_epochs, temperature_threshold, update_threshold
         self.num_workers, self.mcts_threads, self.arena_games = num_workers, mcts_threads, arena_games
         self.nn_mode, self.num_channels, self.num_res_blocks = nn_mode, num_channels, num_res_blocks
         self.concurrent_games = concurrent_games
+        self.lr, self.batch_size = lr, batch_size
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         for d in (model_dir, data_dir):
             os.makedirs(d, exist_ok=True)
         self.current_model_path = os.path.join(model_dir, "current_model.pth.tar")
         self.best_model_path = os.path.join(model_dir, "best_model.pth.tar")
-        if not os.path.exists(self.current_model_path):
-            YinYangNeuralNetwork(game, num_channels, num_res_blocks).save_model(self.current_model_path)
-        if not os.path.exists(self.best_model_path):
-            shutil.copy(self.current_model_path, self.best_model_path)
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            if not os.path.exists(self.current_model_path):
+                YinYangNeuralNetwork(game, num_channels, num_res_blocks).save_model(self.current_model_path)
+            if not os.path.exists(self.best_model_path):
+                shutil.copy(self.current_model_path, self.best_model_path)
+        if multi:
+            dist.barrier()
         self.history = []
 
     def self_play(self, model_path):
@@ -204,26 +210,49 @@ class AlphaZero:
                                        concurrent_games=self.concurrent_games, seed=len(self.history))
 
     def train(self):
-        # the reference passes num_iterations=1 and ignores --epochs (alphazero.py:120-127); epochs are honoured here
+        # the reference passes num_iterations=1 and ignores --epochs/--batch-size/--lr (alphazero.py:120-127,
+        # train_alphazero.py:42-44); they are honoured here
         new_path = run_training_pipeline(self.game, self.model_dir, self.data_dir, num_iterations=1, sample_size=10000,
                                          checkpoint_interval=1, epochs_per_iteration=self.num_epochs, device=self.device,
-                                         num_channels=self.num_channels, num_res_blocks=self.num_res_blocks)
-        shutil.copy(new_path, self.current_model_path)
+                                         num_channels=self.num_channels, num_res_blocks=self.num_res_blocks,
+                                         lr=self.lr, batch_size=self.batch_size)
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            shutil.copy(new_path, self.current_model_path)
+        if multi:
+            dist.barrier()
         return self.current_model_path
 
     def evaluate(self, current_model_path, best_model_path, num_games=None):
+        """alphazero.py:136-226.  Multi-rank: the match is sharded (2 games per colour pair at a time) and the win
+        counts are summed with one all-reduce, so every rank takes the same promote decision."""
+        import torch.distributed as dist
         n = self.arena_games if num_games is None else num_games
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+        pairs = n // 2                                   # keep colours balanced inside every shard
+        mine = 2 * (pairs // world + (1 if rank < pairs % world else 0)) + (n % 2 if rank == 0 else 0)
         cur = _load_evaluator(self.game, current_model_path, self.device, self.nn_mode, self.num_channels, self.num_res_blocks)
         best = _load_evaluator(self.game, best_model_path, self.device, self.nn_mode, self.num_channels, self.num_res_blocks)
-        res = Arena(self.game, cur, best, self.num_simulations, device=self.device, seed=len(self.history)).play(n)
+        res = (Arena(self.game, cur, best, self.num_simulations, device=self.device, seed=len(self.history) * 131 + rank).play(mine)
+               if mine > 0 else dict(a_wins=0, b_wins=0, draws=0, games=0))
+        if multi:
+            t = torch.tensor([res["a_wins"], res["b_wins"], res["draws"], res["games"]], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t)
+            res = dict(a_wins=int(t[0]), b_wins=int(t[1]), draws=int(t[2]), games=int(t[3]))
         self.last_arena = res
-        return res["a_wins"] / n
+        return res["a_wins"] / max(1, res["games"])
 
     def update_best_model(self, win_ratio):
-        if win_ratio >= self.update_threshold:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        promote = win_ratio >= self.update_threshold
+        if promote and (not multi or dist.get_rank() == 0):
             shutil.copy(self.current_model_path, self.best_model_path)
-            return True
-        return False
+        if multi:
+            dist.barrier()
+        return promote
 
     def run(self):
         import time

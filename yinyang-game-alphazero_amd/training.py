@@ -94,13 +94,31 @@ class TrainingDataQueue:
             return {}
         k = min(self.sample_size if sample_size is None else sample_size, n)
         idx = torch.tensor(random.sample(range(n), k), dtype=torch.long)     # random.sample like :95
+        dist = _dist()
+        if dist:                                                             # every rank trains on the same sample
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            idx = idx.to(dev)
+            dist.broadcast(idx, src=0)
+            idx = idx.cpu()
         return dict(states=self.states[idx], policies=self.policies[idx], values=self.values[idx])
 
     def __len__(self):
         return 0 if self.states is None else int(self.states.shape[0])
 
 
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
 class AlphaZeroTrainer:
+    """trainer.py:15-212.  Under a multi-rank job (torchrun, one process per GPU) the module is wrapped in
+    DistributedDataParallel: every rank holds the same (all-gathered) examples, trains on its 1/world slice of each
+    epoch's permutation with batch_size // world samples per step, gradients are all-reduced (RCCL), and rank 0
+    writes the checkpoints -- the global batch and the optimiser schedule match the single-process run."""
+
     def __init__(self, game, model_dir="models", lr=0.001, batch_size=64, weight_decay=1e-4, device=None,
                  num_channels=128, num_res_blocks=10):
         self.game, self.model_dir, self.batch_size = game, model_dir, batch_size
@@ -108,6 +126,7 @@ class AlphaZeroTrainer:
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.nnet = YinYangNeuralNetwork(game, num_channels, num_res_blocks).to(self.device)
         self.optimizer = torch.optim.Adam(self.nnet.parameters(), lr=lr, weight_decay=weight_decay)
+        self._ddp = None
 
     def _encode(self, states):
         """int8 [N,R,C] -> planes f32 [N,5,R,C]: HIP encode kernel on a ROCm device, torch ops on CPU."""
@@ -135,21 +154,41 @@ class AlphaZeroTrainer:
             val = val.repeat(8)
         n = planes.shape[0]
         metrics = {"policy_loss": [], "value_loss": [], "total_loss": []}
+        dist = _dist()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+        model = self.nnet
+        if dist:
+            if self._ddp is None:
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                self._ddp = DDP(self.nnet, device_ids=[self.device.index] if self.device.type == "cuda" else None)
+            model = self._ddp
         self.nnet.train()
         for _ in range(epochs):
             perm = torch.randperm(n, device=self.device)
-            sums = torch.zeros(3, device=self.device)
+            if dist:                                  # the same permutation everywhere, then a disjoint slice per rank
+                dist.broadcast(perm, src=0)
+            sums = torch.zeros(4, device=self.device)
             for i in range(0, n, self.batch_size):
-                idx = perm[i:i + self.batch_size]
+                gidx = perm[i:i + self.batch_size]
+                idx = gidx[rank::world]
                 self.optimizer.zero_grad(set_to_none=True)
-                logits, v = self.nnet(planes[idx])
+                if idx.numel() == 0:                  # ragged tail: contribute a zero gradient, keep the collective in step
+                    logits, v = model(planes[gidx[:1]])
+                    loss = (logits.sum() + v.sum()) * 0.0
+                    loss.backward()
+                    self.optimizer.step()
+                    continue
+                logits, v = model(planes[idx])
                 p_loss = F.cross_entropy(logits, pol[idx])               # soft targets, trainer.py:130
                 v_loss = F.mse_loss(v.reshape(-1), val[idx])             # :131
                 loss = p_loss + v_loss
-                loss.backward()
+                # DDP averages gradients over ranks; weight by this rank's share so the step equals the full-batch mean
+                (loss * (idx.numel() * world / gidx.numel()) if dist else loss).backward()
                 self.optimizer.step()
-                sums += torch.stack([p_loss.detach(), v_loss.detach(), loss.detach()]) * idx.numel()
-            pl, vl, tl = (sums / n).tolist()
+                sums += torch.stack([p_loss.detach(), v_loss.detach(), loss.detach(), torch.ones((), device=self.device)]) * idx.numel()
+            if dist:
+                dist.all_reduce(sums)
+            pl, vl, tl = (sums[:3] / sums[3].clamp_min(1)).tolist()
             metrics["policy_loss"].append(pl)
             metrics["value_loss"].append(vl)
             metrics["total_loss"].append(tl)
@@ -162,7 +201,11 @@ class AlphaZeroTrainer:
         return os.path.join(self.model_dir, filename)
 
     def save_checkpoint(self, filename=None, iteration=None):
-        self.nnet.save_model(self._path(filename, iteration))
+        dist = _dist()
+        if dist is None or dist.get_rank() == 0:
+            self.nnet.save_model(self._path(filename, iteration))
+        if dist:
+            dist.barrier()          # the file exists before any rank goes on to read it
 
     def load_checkpoint(self, filename=None, iteration=None):
         path = self._path(filename, iteration)
