@@ -100,7 +100,7 @@ assert os.path.exists(os.path.join(sys.argv[2], "checkpoint_1.pth.tar"))
 q = pkg.TrainingDataQueue(sample_size=5); q.push_examples(ex)
 s = q.sample(); ids = s["values"].clone(); ref2 = ids.clone(); dist.broadcast(ref2, src=0)
 assert torch.equal(ids, ref2), "ranks sampled different examples"
-print("rank", r, "ok", [round(x, 4) for x in m["total_loss"]])
+sys.stdout.write("rank %d ok %s\n" % (r, [round(x, 4) for x in m["total_loss"]])); sys.stdout.flush()
 dist.destroy_process_group()
 '''
 
@@ -115,5 +115,6 @@ def test_trainer_ddp_gloo_world2(tmp_path):
                         "127.0.0.1", "--master-port", "29573", str(script), root, str(tmp_path / "m")],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("rank")]
-    assert len(lines) == 2 and lines[0].split("ok")[1] == lines[1].split("ok")[1]      # same global loss on both ranks
+    import re
+    losses = re.findall(r"ok (\[[^\]]*\])", r.stdout)
+    assert len(losses) == 2 and losses[0] == losses[1], r.stdout[-500:]      # same global loss on both ranks
