@@ -297,7 +297,7 @@ def main():
             tower_flops = (2 * 9 * 16 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)
                            + (2 * 128 * 64 * cells if getattr(eng.evaluator, "fused_heads", False) else 0)) * args.games
             ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": ("k_tower" if args.rows == 8 else "k_tower12") + " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)",
+            roof = {"bound": "mfma", "kernel": {6: "k_tower6", 8: "k_tower", 12: "k_tower12"}.get(args.rows, "k_tower") + " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)",
                     "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": None, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
             extra["roofline_tree_kernel"] = roof_tree

@@ -123,14 +123,15 @@ def test_tower_kernel_matches_torch_bf16_path():
         assert float((p_h - p_t).abs().max()) < 2e-2 and float((v_h - v_t).abs().max()) < 5e-2
 
 
-def test_tower12_kernel_matches_torch_bf16_path():
-    """12x12 variant (csrc/yy_tower12.hip): same checks as the 8x8 kernel -- tower activations within 2 bf16 ulps of
+@pytest.mark.parametrize("R", [12, 6])
+def test_tower_other_sizes_match_torch_bf16_path(R):
+    """12x12 (csrc/yy_tower12.hip) and 6x6 (csrc/yy_tower6.hip) variants: same checks as the 8x8 kernel -- tower activations within 2 bf16 ulps of
     scale per layer against torch bf16 convolutions on the same folded weights, fused head features within 2 ulps,
     end-to-end policy 2e-2 / value 5e-2 abs against the torch bf16 path and the fp32 module."""
     import torch
     import yinyang_game_alphazero_amd as pkg
     torch.manual_seed(1)
-    game = pkg.YinYangGame(12, 12)
+    game = pkg.YinYangGame(R, R)
     rng = np.random.default_rng(4)
     for blocks, G in ((1, 5), (10, 67)):
         net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
@@ -143,7 +144,7 @@ def test_tower12_kernel_matches_torch_bf16_path():
                     m.bias.normal_(0, 0.1)
                 if isinstance(m, torch.nn.Conv2d):
                     m.bias.normal_(0, 0.05)
-        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 12, 12)).astype(np.int8)).cuda()
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda()
         planes = pkg.engine.encode_planes(boards)
         ref = pkg.BatchedEvaluator(net, "bf16", tower=False)
         tow = pkg.BatchedEvaluator(net, "bf16", tower=True, fused_heads=False)
@@ -166,5 +167,5 @@ def test_tower12_kernel_matches_torch_bf16_path():
         p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
         for ev in (tow, towh):
             p, v = ev(planes)
-            assert p.shape == (G, 144) and float((p - p_r).abs().max()) < 2e-2 and float((v - v_r).abs().max()) < 5e-2
+            assert p.shape == (G, R * R) and float((p - p_r).abs().max()) < 2e-2 and float((v - v_r).abs().max()) < 5e-2
             assert float((p - p32).abs().max()) < 2e-2 and float((v - v32).abs().max()) < 5e-2

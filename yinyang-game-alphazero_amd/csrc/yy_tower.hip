@@ -344,15 +344,19 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
 extern "C" int yy_tower12_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
                                  int G, int n_layers, yy_stream_t s);   // yy_tower12.hip: 12x12 boards
 
+extern "C" int yy_tower6_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
+                                int G, int n_layers, yy_stream_t s);   // yy_tower6.hip: 6x6 boards
+
 static int launch_tower(const float *planes, const void *weights, const float *bias, void *out, void *out_heads, int G,
                         int R, int C, int channels, int n_layers, yy_stream_t s) {
     if (G == 0) return YY_OK;
     if (!planes || !weights || !bias || (!out && !out_heads) || G < 0)
         return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower: bad argument");
-    const bool b8 = (R == 8 && C == 8), b12 = (R == 12 && C == 12);
-    if (!(b8 || b12) || channels != TW_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > TW_MAX_LAYERS || (n_layers & 1) == 0)
-        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
+    const bool b8 = (R == 8 && C == 8), b12 = (R == 12 && C == 12), b6 = (R == 6 && C == 6);
+    if (!(b8 || b12 || b6) || channels != TW_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > TW_MAX_LAYERS || (n_layers & 1) == 0)
+        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
     if (b12) return yy_tower12_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
+    if (b6) return yy_tower6_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
     const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
     const unsigned char *w = (const unsigned char *)weights;
