@@ -173,17 +173,18 @@ int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_
                         int relu, yy_stream_t stream);
 
 /* The residual tower of the evaluator (stem + residual blocks, ai/neural_network.py:16-33, 105-110)
- * as ONE LDS-resident MFMA kernel: planes float32 [G,5,8,8] -> out bf16 [G,8,8,128] (channels-last
+ * as ONE LDS-resident MFMA kernel: planes float32 [G,5,R,R] -> out bf16 [G,R,R,128] (channels-last
  * activations after the last block).  weights: bf16 chunks in fragment order and bias float32
  * [n_layers,128], both produced on the host from the module with eval-mode BatchNorm folded
- * (network.pack_tower).  n_layers = 1 + 2*res_blocks.  8x8 boards and 128 channels only
- * (YY_E_UNSUPPORTED otherwise). */
+ * (network.pack_tower).  n_layers = 1 + 2*res_blocks <= 21.  Boards 6x6, 8x8 or 12x12 (planes
+ * [G,5,R,R], out [G,R,R,128]) and 128 channels; anything else returns YY_E_UNSUPPORTED and the
+ * caller uses library convolutions + yy_nn_bias_act_bf16. */
 int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G,
                      int R, int C, int channels, int n_layers, yy_stream_t stream);
 
 /* Same kernel, with the policy_conv / value_conv 1x1 head convolutions + BatchNorm + ReLU
- * (neural_network.py:113, 118) fused behind the tower: out_heads bf16 [G,2,32,64] = [policy features,
- * value features] in the reference's NCHW flatten order (channel*64 + cell, :114 / :119), ready for
+ * (neural_network.py:113, 118) fused behind the tower: out_heads bf16 [G,2,32,R*R] = [policy features,
+ * value features] in the reference's NCHW flatten order (channel*R*R + cell, :114 / :119), ready for
  * policy_fc / value_fc1.  weights holds one extra 16 KB chunk ([ks 8][nt 2][h 2][c 32][j 8]) and bias
  * one extra row [n_layers] = [policy bias 32 | value bias 32 | 0...]. */
 int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float *bias,
