@@ -186,7 +186,7 @@ class BatchedEvaluator:
         # the LDS-resident MFMA tower kernels (csrc/yy_tower.hip 8x8, yy_tower12.hip 12x12, yy_tower6.hip 6x6) cover the stem + residual
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
-                      and net.conv1.out_channels == 128 and 1 + 2 * len(net.res_blocks) <= 23)
+                      and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
         if mode != "fp32":
             self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
             self._fold()
