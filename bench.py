@@ -306,7 +306,8 @@ def main():
         flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
                       + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
         extra = {**extra, "nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
-                 "tree_kernel_ms": k_ms, "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
+                 "tree_kernel_ms": k_ms, "tree_kernel_only_expansions_per_s": kc["evals"] / max(n_launch, 1) / (k_ms * 1e-3),
+                 "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
         if not args.no_cpu_baseline:
             cpub = cpu_baseline(args)
     if dist is not None:
