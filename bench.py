@@ -27,6 +27,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA ~2.5 PFLOP/s dense
+MFMA_F32_PEAK_TFLOPS = 157.3    # same guide: f32-input MFMA = the f32 vector rate
 
 
 def parse():
@@ -40,7 +41,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=8)
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32", "fp32t"])
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -151,6 +152,14 @@ def roofline_pass(eng):
     # the tower kernel alone (HIP events on its launch stream), when the evaluator uses it
     tower_ms = None
     ev = eng.evaluator
+    if getattr(ev, "mode", "") == "fp32t":
+        from yinyang_game_alphazero_amd import engine as E
+        tt = HipEventTimer(5)
+        for _ in range(5):
+            tt.start()
+            E.tower_forward_f32(eng.ctx.planes, ev.f32_w, ev.f32_b, ev.f32_layers)
+            tt.stop()
+        tower_ms, _ = tt.mean_ms()
     if getattr(ev, "tower", False):
         from yinyang_game_alphazero_amd import engine as E
         tt = HipEventTimer(reps)
@@ -297,8 +306,16 @@ def main():
             tower_flops = (2 * 9 * 16 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)
                            + (2 * 128 * 64 * cells if getattr(eng.evaluator, "fused_heads", False) else 0)) * args.games
             ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": {6: "k_tower6", 8: "k_tower", 12: "k_tower12"}.get(args.rows, "k_tower") + " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)",
-                    "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            f32t = args.nn == "fp32t"
+            if f32t:   # exact-f32 kernel: K of the stem padded to 8, no fused heads
+                tower_flops = (2 * 9 * 8 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)) * args.games
+                ach = tower_flops / (tower_ms * 1e-3) / 1e12
+            peak = MFMA_F32_PEAK_TFLOPS if f32t else MFMA_BF16_PEAK_TFLOPS
+            name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
+                {6: "k_tower6", 8: "k_tower", 12: "k_tower12"}.get(args.rows, "k_tower") + \
+                " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
+            roof = {"bound": "mfma", "kernel": name,
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": None, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
             extra["roofline_tree_kernel"] = roof_tree
         A = args.rows * args.cols

@@ -191,6 +191,13 @@ int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float
                            void *out_heads, int G, int R, int C, int channels, int n_layers,
                            yy_stream_t stream);
 
+/* The residual tower in EXACT float32 on the f32-input MFMA (v_mfma_f32_32x32x2_f32; a k-ordered fmaf chain,
+ * bitwise f32): the fast form of the fp32 parity evaluator.  planes float32 [G,5,8,8] -> out float32 [G,8,8,128]
+ * (channels-last activations after the last block); weights float32 chunks in fragment order and bias float32
+ * [n_layers,128] from network.pack_tower_f32.  8x8 boards, 128 channels. */
+int yy_nn_tower_f32(const float *planes, const void *weights, const float *bias, float *out, int G,
+                    int R, int C, int channels, int n_layers, yy_stream_t stream);
+
 /* Head finish (neural_network.py:115, 120-121, 152): h bf16 [G, A+H] = policy logits then value_fc1
  * outputs (bias added); policy float32 [G,A] = softmax(logits); value float32 [G] =
  * tanh(relu(hidden) . w2 + b2) with w2 float32 [H], b2 float32 [1]. */

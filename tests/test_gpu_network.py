@@ -169,3 +169,39 @@ def test_tower_other_sizes_match_torch_bf16_path(R):
             p, v = ev(planes)
             assert p.shape == (G, R * R) and float((p - p_r).abs().max()) < 2e-2 and float((v - v_r).abs().max()) < 5e-2
             assert float((p - p32).abs().max()) < 2e-2 and float((v - v32).abs().max()) < 5e-2
+
+
+def test_f32_tower_kernel_matches_fp32_module():
+    """csrc/yy_tower_f32.hip (exact float32 on v_mfma_f32_32x32x2_f32) against the fp32 nn.Module on the same device.
+    Same weights (BatchNorm folded on the host in float32), so the two differ only by summation order and the
+    folding: activations within 1e-4 relative to the layer scale, policy 1e-5 / value 1e-4 abs (north-star 1e-5 on pi)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(2)
+    torch.backends.cudnn.allow_tf32 = False
+    game = pkg.YinYangGame(8, 8)
+    rng = np.random.default_rng(5)
+    for blocks, G in ((1, 3), (10, 70)):
+        net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.1)
+                if isinstance(m, torch.nn.Conv2d):
+                    m.bias.normal_(0, 0.05)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        ev = pkg.BatchedEvaluator(net, "fp32t")
+        x_t = pkg.engine.tower_forward_f32(planes, ev.f32_w, ev.f32_b, ev.f32_layers)
+        with torch.no_grad():
+            x = torch.relu(net.bn1(net.conv1(planes)))
+            for blk in net.res_blocks:
+                x = blk(x)
+        scale = float(x.abs().max())
+        assert float((x_t - x).abs().max()) <= 1e-4 * scale, (blocks, float((x_t - x).abs().max()), scale)
+        p, v = ev(planes)
+        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+        assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4

@@ -154,6 +154,28 @@ def pack_tower(net):
     return wq, torch.stack(biases).contiguous()
 
 
+def pack_tower_f32(net):
+    """float32 packing for csrc/yy_tower_f32.hip: chunk = one tap x 32 input channels = [m 4][nt 4][h 2][i 32][s 4]
+    float32 with cout = nt*32 + i and cin = quarter*32 + m*8 + h*4 + s; the stem has one chunk per tap (5 planes padded to
+    8 channels, m = 0 only), every other layer 36 (tap-major, then quarter)."""
+    convs = [(net.conv1, net.bn1)]
+    for blk in net.res_blocks:
+        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    chunks, biases = [], []
+    for li, (conv, bn) in enumerate(convs):
+        w, b = fold_batchnorm(conv, bn)
+        w = w.float().cpu()
+        wp = torch.zeros((128, 128, 3, 3))
+        wp[:, :w.shape[1]] = w
+        for tap in range(9):
+            t = wp[:, :, tap // 3, tap % 3].reshape(4, 32, 4, 4, 2, 4)      # nt, i, quarter, m, h, s
+            t = t.permute(2, 3, 0, 4, 1, 5).contiguous()                   # quarter, m, nt, h, i, s
+            for quarter in range(1 if li == 0 else 4):
+                chunks.append(t[quarter].reshape(-1))
+        biases.append(b.float().cpu())
+    return torch.stack(chunks).contiguous(), torch.stack(biases).contiguous()
+
+
 def pack_heads(net):
     """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
     [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
@@ -171,6 +193,8 @@ class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
     mode "fp32": the module as is (parity path: same arithmetic as predict()).
+    mode "fp32t": the same float32 weights, but the stem + residual tower run in the hand-written exact-f32 MFMA kernel
+    (csrc/yy_tower_f32.hip; 8x8 boards, 128 channels); heads by torch in float32.  Differs from "fp32" only by summation order.
     mode "bf16"/"fp16": inference-only fast path -- eval-mode BatchNorm folded into the convs,
     channels-last activations, reduced-precision MFMA convolutions (MIOpen implicit GEMM), softmax/tanh
     in fp32.  In bf16 mode with `fused_epilogue` (default) every convolution is issued WITHOUT bias and
@@ -187,6 +211,15 @@ class BatchedEvaluator:
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
                       and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
+        if mode == "fp32t":
+            if tuple(net.board_size) != (8, 8) or net.conv1.out_channels != 128 or len(net.res_blocks) > 11:
+                raise ValueError("fp32t needs 8x8 boards, 128 channels, at most 11 residual blocks")
+            wq, bq = pack_tower_f32(net)
+            self.f32_w, self.f32_b = wq.to(self.device), bq.to(self.device)
+            self.f32_layers = 1 + 2 * len(net.res_blocks)
+            self.f32_heads = (fold_batchnorm(net.policy_conv, net.policy_bn), fold_batchnorm(net.value_conv, net.value_bn))
+            self.tower = False
+            return
         if mode != "fp32":
             self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
             self._fold()
@@ -241,6 +274,16 @@ class BatchedEvaluator:
     def __call__(self, planes):
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
+        if self.mode == "fp32t":
+            from . import engine
+            n = self.net
+            x = engine.tower_forward_f32(planes, self.f32_w, self.f32_b, self.f32_layers)
+            (pw, pb), (vw, vb) = self.f32_heads
+            p = F.relu(F.conv2d(x, pw, pb)).contiguous().flatten(1)
+            v = F.relu(F.conv2d(x, vw, vb)).contiguous().flatten(1)
+            logits = n.policy_fc(p)
+            value = torch.tanh(n.value_fc2(F.relu(n.value_fc1(v)))).reshape(-1)
+            return F.softmax(logits, dim=1), value
         if self.tower and self.fused_heads:
             from . import engine
             feats = engine.tower_heads_forward(planes, self.towerh_w, self.towerh_b, self.tower_layers)
