@@ -205,3 +205,21 @@ def test_f32_tower_kernel_matches_fp32_module():
         p, v = ev(planes)
         p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
         assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4
+
+
+def test_gpu_evaluators_against_reference_recorded_outputs():
+    """The reference's own (board -> policy, value) pairs (search_net_8x8.npz, CPU fp32, seed 0) against the mirror on the
+    GPU: fp32 module and the exact-f32 tower within 1e-5 on policy / 1e-4 on value; bf16 tower within 2e-2 / 5e-2."""
+    import os
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_net_8x8.npz"))
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
+    n = int(z["n_rec"][1])
+    boards = torch.from_numpy(z["rec_boards"][1, :n]).cuda()
+    rp, rv = torch.from_numpy(z["rec_policy"][1, :n]).cuda(), torch.from_numpy(z["rec_value"][1, :n]).cuda()
+    planes = pkg.engine.encode_planes(boards)
+    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
+        p, v = pkg.BatchedEvaluator(net, mode)(planes)
+        assert float((p - rp).abs().max()) < tp and float((v - rv).abs().max()) < tv, mode

@@ -146,3 +146,26 @@ def test_shard_games_partitions_every_world_size():
                 n, first, stride = shard_games(total, r, world)
                 ids += [first + i * stride for i in range(n)]
             assert sorted(ids) == list(range(total)), (total, world)
+
+
+def test_network_mirror_reproduces_reference_outputs():
+    """search_net_8x8.npz holds (board -> policy, value) pairs recorded from the REFERENCE's YinYangNeuralNetwork
+    (torch.manual_seed(0), default 128 x 10, CPU) while it searched.  The mirror built with the same seed must have the
+    same weights (same module construction and init order) and give the same outputs on the CPU: policy within 1e-6,
+    value within 1e-6 (same torch build, so in practice identical up to thread-count-dependent summation order)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    z = np.load(os.path.join(ROOT, "tests", "golden", "search_net_8x8.npz"))
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).eval()
+    n = int(z["n_rec"][0])
+    boards, rp, rv = z["rec_boards"][0, :n], z["rec_policy"][0, :n], z["rec_value"][0, :n]
+    import oracle_lib as O
+    p, v = net.predict_batch(torch.from_numpy(O.encode_planes(boards[:24])))
+    assert float(np.abs(p.numpy() - rp[:24]).max()) < 1e-6
+    assert float(np.abs(v.numpy() - rv[:24]).max()) < 1e-6
+    # and through the single-board API of the reference
+    lb = pkg.YinYangLogic(8, 8)
+    lb.board = boards[5].copy()
+    p1, v1 = net.predict(lb)
+    assert float(np.abs(p1 - rp[5]).max()) < 1e-6 and abs(float(v1) - float(rv[5])) < 1e-6
