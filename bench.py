@@ -314,9 +314,14 @@ def main():
             name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
                 {6: "k_tower6", 8: "k_tower", 12: "k_tower12"}.get(args.rows, "k_tower") + \
                 " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
+            ttraffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same G, same kernel)
+            tpmc = os.path.join(ROOT, "profiles", "r01_k_tower_hbm_pmc.json")
+            if os.path.exists(tpmc) and not f32t and getattr(eng.evaluator, "fused_heads", False) and \
+                    (args.games, args.rows, args.cols, args.channels, args.blocks) == (4096, 8, 8, 128, 10):
+                ttraffic = json.load(open(tpmc))["per_launch_bytes"]["traffic_corrected"]
             roof = {"bound": "mfma", "kernel": name,
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": None, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
+                    "traffic": ttraffic, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
             extra["roofline_tree_kernel"] = roof_tree
         A = args.rows * args.cols
         Cc = args.channels
@@ -325,7 +330,7 @@ def main():
         extra = {**extra, "nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
                  "tree_kernel_ms": k_ms, "tree_kernel_only_expansions_per_s": kc["evals"] / max(n_launch, 1) / (k_ms * 1e-3),
                  "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             cpub = cpu_baseline(args)
     if dist is not None:
         dist.barrier()

@@ -533,6 +533,10 @@ def main():
         gen_g4(pool)
     if "g6" in only:
         gen_g6()
+    if "edge" in only:      # degenerate and maximum geometries (1 x N, N x 1, 2 x 2, the 192-cell / 16-wide limits)
+        gen_g1([(1, 1), (1, 6), (7, 1), (2, 2), (2, 9), (13, 14), (16, 12), (12, 16)], 256, pool)
+        gen_g2([(1, 6), (7, 1), (16, 12)], 64)
+        gen_g3([(1, 6), (2, 2), (7, 1), (16, 12), (12, 16)], pool)
     pool.close()
 
 
