@@ -312,7 +312,7 @@ def main():
                 ach = tower_flops / (tower_ms * 1e-3) / 1e12
             peak = MFMA_F32_PEAK_TFLOPS if f32t else MFMA_BF16_PEAK_TFLOPS
             name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
-                {6: "k_tower6", 8: "k_tower", 12: "k_tower12"}.get(args.rows, "k_tower") + \
+                {6: "k_towerq<6,8>", 8: "k_tower" if args.games > 512 else "k_towerq<8,%d>" % (1 if args.games <= 256 else 2), 12: "k_tower12"}.get(args.rows, "k_tower") + \
                 " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
             ttraffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same G, same kernel)
             tpmc = os.path.join(ROOT, "profiles", "r01_k_tower_hbm_pmc.json")

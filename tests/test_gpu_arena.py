@@ -25,6 +25,63 @@ def test_arena_accounting_and_symmetry():
     assert res3["a_wins"] + res3["b_wins"] + res3["draws"] == 32 and res3["a_wins"] > 0 and res3["b_wins"] > 0
 
 
+def test_arena_graph_replay_equals_routed_eager():
+    """A small match runs both players on all rows and replays the simulation step from a hipGraph; a large one routes
+    rows to their own network eagerly.  With evaluators whose output depends on the row only (exact hash evaluators)
+    both must play the same games."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd import arena as arena_mod
+    from hash_eval import hash_eval_torch
+    game = pkg.YinYangGame(6, 6)
+    ev_a = lambda planes: hash_eval_torch(planes, 10, 11)
+    ev_b = lambda planes: hash_eval_torch(planes, 6, 4)
+    res_graph = pkg.Arena(game, ev_a, ev_b, num_simulations=30, seed=5).play(10)
+
+    class Routed(arena_mod.DualEvaluator):
+        def __init__(self, *a, **k):
+            k["dense"] = False
+            super().__init__(*a, **k)
+
+    class EagerSearch(arena_mod.LockstepSearch):
+        def __init__(self, ctx, ev, use_graph=True):
+            super().__init__(ctx, ev, use_graph=False)
+
+    saved = arena_mod.DualEvaluator, arena_mod.LockstepSearch
+    arena_mod.DualEvaluator, arena_mod.LockstepSearch = Routed, EagerSearch
+    try:
+        res_eager = pkg.Arena(game, ev_a, ev_b, num_simulations=30, seed=5).play(10)
+    finally:
+        arena_mod.DualEvaluator, arena_mod.LockstepSearch = saved
+    assert res_graph == res_eager and res_graph["games"] == 10
+
+
+def test_trainer_graph_step_matches_eager():
+    """The hipGraph-replayed optimiser step (single process, full batches) against the eager loop: same data, same
+    permutations, same initial weights -> same losses (tolerance 2e-3 relative: the captured step may use other MIOpen
+    convolution algorithms, i.e. another summation order, than the eager one)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(6, 6)
+    rng = np.random.default_rng(0)
+    n = 96
+    ex = dict(states=torch.from_numpy(rng.integers(-1, 2, size=(n, 6, 6)).astype(np.int8)),
+              policies=torch.from_numpy(rng.dirichlet(np.ones(36), size=n).astype(np.float32)),
+              values=torch.from_numpy(rng.choice([-1.0, 1.0, 1e-4], size=n).astype(np.float32)))
+    losses = []
+    for graph in (True, False):
+        torch.manual_seed(3)
+        tr = pkg.AlphaZeroTrainer(game, model_dir="/tmp/yy_graph_step_test", batch_size=32, device="cuda",
+                                  num_channels=16, num_res_blocks=2, graph_step=graph)
+        torch.manual_seed(4)                      # the epoch permutations
+        m = tr.train(ex, epochs=3, augment=True)  # 768 samples = 24 full batches per epoch
+        assert (tr._graph is not None) == graph
+        losses.append(m["total_loss"])
+    a, b = np.asarray(losses[0]), np.asarray(losses[1])
+    assert np.all(np.abs(a - b) <= 2e-3 * np.abs(b)), (a, b)
+    assert a[-1] < a[0]
+
+
 def test_alphazero_one_iteration(tmp_path):
     """config 5 in miniature: GPU self-play -> training -> arena -> promote decision; files keep the
     reference's names and checkpoint format."""

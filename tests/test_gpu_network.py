@@ -70,7 +70,8 @@ def test_tower_kernel_matches_torch_bf16_path():
     torch.manual_seed(0)
     game = pkg.YinYangGame(8, 8)
     rng = np.random.default_rng(3)
-    for blocks, G in ((1, 7), (3, 64), (10, 130)):
+    # G picks the kernel: <= 256 one board per workgroup, <= 512 two (yy_towerq.hip), above that four (yy_tower.hip)
+    for blocks, G in ((1, 7), (3, 300), (10, 130), (10, 1030)):
         net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
         # non-trivial BatchNorm statistics and biases so that folding and the bias path are exercised
         with torch.no_grad():
@@ -121,6 +122,27 @@ def test_tower_kernel_matches_torch_bf16_path():
         assert float((pk - pt).abs().max()) < 1e-6 and float((vk - vt).abs().max()) < 1e-5
         p_h, v_h = towh(planes)
         assert float((p_h - p_t).abs().max()) < 2e-2 and float((v_h - v_t).abs().max()) < 5e-2
+
+
+def test_tower_small_batch_kernels_bit_identical_to_main():
+    """8x8: the 1- and 2-boards-per-workgroup kernels (small batches) and the 4-boards-per-workgroup kernel run the same
+    accumulation order and epilogue, so a board's output must not depend on the batch it is evaluated in: exact."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(1)
+    net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8), 128, 10).cuda().eval()
+    ev = pkg.BatchedEvaluator(net, "bf16")
+    rng = np.random.default_rng(11)
+    planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(1100, 8, 8)).astype(np.int8)).cuda())
+    full_h = pkg.engine.tower_heads_forward(planes, ev.towerh_w, ev.towerh_b, ev.tower_layers)       # 4 boards / workgroup
+    full_x = pkg.engine.tower_forward(planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+    assert float(full_h.float().abs().max()) > 0
+    for g in (1, 3, 64, 255, 256, 257, 301, 512):                                                   # 1 and 2 boards / workgroup
+        sub = planes[:g].contiguous()
+        h = pkg.engine.tower_heads_forward(sub, ev.towerh_w, ev.towerh_b, ev.tower_layers)
+        x = pkg.engine.tower_forward(sub, ev.tower_w, ev.tower_b, ev.tower_layers)
+        assert torch.equal(h.view(torch.int16), full_h[:g].view(torch.int16)), g
+        assert torch.equal(x.view(torch.int16), full_x[:g].view(torch.int16)), g
 
 
 @pytest.mark.parametrize("R", [12, 6])

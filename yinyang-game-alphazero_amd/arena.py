@@ -26,19 +26,42 @@ from .training import run_training_pipeline
 
 
 class DualEvaluator:
-    """Routes each row of the leaf batch to evaluator A or B (fixed during one search)."""
+    """Gives each row of the leaf batch the output of evaluator A or B (fixed during one search).
 
-    def __init__(self, ev_a, ev_b, G, A, device):
-        self.ev_a, self.ev_b = ev_a, ev_b
+    Two modes.  `dense` (small matches): both networks run on ALL rows and a device-side row mask picks the output, so
+    the step has no host-dependent shapes and the simulation loop can be replayed from a hipGraph (a 40-game arena is
+    launch-bound, not compute-bound).  Routed (large matches): each network sees only its own rows (index_select /
+    index_copy), eager launches."""
+
+    def __init__(self, ev_a, ev_b, G, A, device, dense=False):
+        self.ev_a, self.ev_b, self.dense = ev_a, ev_b, dense
         self.idx_a = self.idx_b = None
+        self.side = None
+        self.sel = torch.ones(G, dtype=torch.bool, device=device)
         self.policy = torch.zeros((G, A), dtype=torch.float32, device=device)
         self.value = torch.zeros(G, dtype=torch.float32, device=device)
 
     def assign(self, a_rows):
-        self.idx_a = a_rows.nonzero(as_tuple=True)[0]
-        self.idx_b = (~a_rows).nonzero(as_tuple=True)[0]
+        self.sel.copy_(a_rows)
+        if not self.dense:
+            self.idx_a = a_rows.nonzero(as_tuple=True)[0]
+            self.idx_b = (~a_rows).nonzero(as_tuple=True)[0]
 
     def __call__(self, planes):
+        if self.dense:
+            # the two forwards are independent and each fills only a few CUs: fork B onto a side stream (capturable),
+            # join before the row select
+            cur = torch.cuda.current_stream(planes.device)
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=planes.device)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                pb, vb = self.ev_b(planes)
+            pa, va = self.ev_a(planes)
+            cur.wait_stream(self.side)
+            torch.where(self.sel[:, None], pa, pb, out=self.policy)
+            torch.where(self.sel, va, vb, out=self.value)
+            return self.policy, self.value
         for idx, ev in ((self.idx_a, self.ev_a), (self.idx_b, self.ev_b)):
             if idx.numel():
                 p, v = ev(planes.index_select(0, idx).contiguous())
@@ -78,9 +101,10 @@ class Arena:
         alive = torch.ones(G, dtype=torch.bool, device=dev)
         ev_a = _uniform_evaluator(self.A) if self.pa == "random" else self.pa
         ev_b = _uniform_evaluator(self.A) if self.pb == "random" else self.pb
-        dual = DualEvaluator(ev_a, ev_b, G, self.A, dev)
+        dense = G <= 1024
+        dual = DualEvaluator(ev_a, ev_b, G, self.A, dev, dense=dense)
         ctx = engine.BatchedMCTS(G, self.R, self.C, max(1, self.sims), cpuct=self.cpuct, rowcol=self.rowcol, device=dev)
-        search = LockstepSearch(ctx, dual, use_graph=False)     # the row routing changes every move
+        search = LockstepSearch(ctx, dual, use_graph=dense)     # routed mode: the row sets change every move
         result = torch.zeros(G, dtype=torch.int8, device=dev)   # +1 black won, -1 white won, 2 draw
         for _ in range(4 * self.A + 8):
             if not bool(alive.any()):

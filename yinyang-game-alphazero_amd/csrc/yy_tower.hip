@@ -47,6 +47,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define TW_MAX_LAYERS 23
 #define TW_ZERO_OFF (TW_BIAS_OFF + TW_MAX_LAYERS * TW_CH * 4)   // 159744, 256 B of zeros
 #define TW_LDS_BYTES 163840
+#define YY_TOWER_TB1_MAX_G 256   // <= one 1-board workgroup per CU
+#define YY_TOWER_TB2_MAX_G 512   // <= one 2-board workgroup per CU
 
 extern "C" int yy_tower_set_err(int code, const char *msg);   // defined in yy_engine.hip
 
@@ -345,7 +347,10 @@ extern "C" int yy_tower12_launch(const float *planes, const void *weights, const
                                  int G, int n_layers, yy_stream_t s);   // yy_tower12.hip: 12x12 boards
 
 extern "C" int yy_tower6_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
-                                int G, int n_layers, yy_stream_t s);   // yy_tower6.hip: 6x6 boards
+                                int G, int n_layers, yy_stream_t s);   // yy_towerq.hip: 6x6 boards
+
+extern "C" int yy_tower8q_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
+                                 int G, int n_layers, int tb, yy_stream_t s);   // yy_towerq.hip: 8x8, 1 or 2 boards per workgroup
 
 static int launch_tower(const float *planes, const void *weights, const float *bias, void *out, void *out_heads, int G,
                         int R, int C, int channels, int n_layers, yy_stream_t s) {
@@ -358,6 +363,11 @@ static int launch_tower(const float *planes, const void *weights, const float *b
     if (b12) return yy_tower12_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     if (b6) return yy_tower6_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
+    static const int force_tb = getenv("YY_TOWER_TB") ? atoi(getenv("YY_TOWER_TB")) : 0;     // timing experiments only
+    // small batches: 4 boards per workgroup would leave most of the 256 CUs idle; spread the boards over more, lighter
+    // workgroups (same results bit for bit)
+    const int tb = force_tb ? force_tb : (G <= YY_TOWER_TB1_MAX_G ? 1 : (G <= YY_TOWER_TB2_MAX_G ? 2 : 4));
+    if (tb == 1 || tb == 2) return yy_tower8q_launch(planes, weights, bias, out, out_heads, G, n_layers, tb, s);
     const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
     const unsigned char *w = (const unsigned char *)weights;
     unsigned short *o = (unsigned short *)out, *oh = (unsigned short *)out_heads;

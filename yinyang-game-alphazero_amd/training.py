@@ -120,13 +120,18 @@ class AlphaZeroTrainer:
     writes the checkpoints -- the global batch and the optimiser schedule match the single-process run."""
 
     def __init__(self, game, model_dir="models", lr=0.001, batch_size=64, weight_decay=1e-4, device=None,
-                 num_channels=128, num_res_blocks=10):
+                 num_channels=128, num_res_blocks=10, graph_step=None):
         self.game, self.model_dir, self.batch_size = game, model_dir, batch_size
         os.makedirs(model_dir, exist_ok=True)
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.nnet = YinYangNeuralNetwork(game, num_channels, num_res_blocks).to(self.device)
-        self.optimizer = torch.optim.Adam(self.nnet.parameters(), lr=lr, weight_decay=weight_decay)
+        # capturable Adam keeps its step counter on the device so the whole step can live in a hipGraph
+        on_gpu = self.device.type == "cuda"
+        self.optimizer = torch.optim.Adam(self.nnet.parameters(), lr=lr, weight_decay=weight_decay,
+                                          **(dict(capturable=True, fused=True) if on_gpu else {}))
         self._ddp = None
+        self.graph_step = self.device.type == "cuda" if graph_step is None else bool(graph_step)
+        self._graph = None
 
     def _encode(self, states):
         """int8 [N,R,C] -> planes f32 [N,5,R,C]: HIP encode kernel on a ROCm device, torch ops on CPU."""
@@ -163,6 +168,7 @@ class AlphaZeroTrainer:
                 self._ddp = DDP(self.nnet, device_ids=[self.device.index] if self.device.type == "cuda" else None)
             model = self._ddp
         self.nnet.train()
+        graphed = self.graph_step and dist is None and self.device.type == "cuda" and n >= self.batch_size
         for _ in range(epochs):
             perm = torch.randperm(n, device=self.device)
             if dist:                                  # the same permutation everywhere, then a disjoint slice per rank
@@ -170,6 +176,9 @@ class AlphaZeroTrainer:
             sums = torch.zeros(4, device=self.device)
             for i in range(0, n, self.batch_size):
                 gidx = perm[i:i + self.batch_size]
+                if graphed and gidx.numel() == self.batch_size:
+                    sums += self._graphed_step(planes, pol, val, gidx) * self.batch_size
+                    continue
                 idx = gidx[rank::world]
                 self.optimizer.zero_grad(set_to_none=True)
                 if idx.numel() == 0:                  # ragged tail: contribute a zero gradient, keep the collective in step
@@ -194,6 +203,51 @@ class AlphaZeroTrainer:
             metrics["total_loss"].append(tl)
         self.nnet.eval()
         return metrics
+
+    def _graphed_step(self, planes, pol, val, gidx):
+        """One full-batch optimiser step (forward, losses, backward, Adam) replayed from a hipGraph: the 128 x 10 network at
+        batch 64 is launch-bound (a few hundred small kernels per step), so the step is captured once into static batch
+        buffers and replayed.  Single-process CUDA only; ragged tail batches and DDP take the eager path.
+        Returns [policy_loss, value_loss, total_loss, 1] of the step (device tensor)."""
+        B = self.batch_size
+        if self._graph is None or self._graph["x"].shape[1:] != planes.shape[1:]:
+            st = dict(x=torch.empty((B,) + tuple(planes.shape[1:]), device=self.device),
+                      p=torch.empty((B, pol.shape[1]), device=self.device), v=torch.empty(B, device=self.device),
+                      out=torch.zeros(4, device=self.device))
+
+            def step():
+                logits, v = self.nnet(st["x"])
+                p_loss = F.cross_entropy(logits, st["p"])
+                v_loss = F.mse_loss(v.reshape(-1), st["v"])
+                loss = p_loss + v_loss
+                loss.backward()
+                self.optimizer.step()
+                return torch.stack([p_loss.detach(), v_loss.detach(), loss.detach(), torch.ones((), device=self.device)])
+
+            for k in ("x", "p", "v"):
+                torch.index_select({"x": planes, "p": pol, "v": val}[k], 0, gidx, out=st[k])
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            # MIOpen's exhaustive find picks the convolution algorithms during the eager step; the capture below hits
+            # that cache (no find runs inside a capture)
+            with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+                with torch.cuda.stream(side):                       # this batch's step runs eagerly once (creates the Adam
+                    self.optimizer.zero_grad(set_to_none=True)      # state, warms the allocator and MIOpen's find) ...
+                    st["out"].copy_(step())
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                self.optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(g):                           # ... then the same step is captured (not executed)
+                    st["out"].copy_(step())
+            st["g"] = g
+            self._graph = st
+            return st["out"].clone()
+        st = self._graph
+        torch.index_select(planes, 0, gidx, out=st["x"])
+        torch.index_select(pol, 0, gidx, out=st["p"])
+        torch.index_select(val, 0, gidx, out=st["v"])
+        st["g"].replay()
+        return st["out"].clone()
 
     def _path(self, filename, iteration):
         if filename is None:
