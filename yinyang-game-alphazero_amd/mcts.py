@@ -104,6 +104,7 @@ class MCTS:
         self.rowcol = bool(getattr(game, "rowcol_rule", False))
         self.device = device
         self._ctx = {}
+        self.use_graph = True          # hipGraph replay of the simulation step for device-resident evaluators
 
     def _context(self, G):
         ctx = self._ctx.get(G)
@@ -115,6 +116,12 @@ class MCTS:
                                      device=self.device)
             self._ctx[G] = ctx
         return ctx
+
+    def _capturable(self, ev):
+        """True for evaluators known to do device work only: the CUDA nn.Module's predict_batch and BatchedEvaluator."""
+        from .network import BatchedEvaluator
+        net = self.neural_net
+        return isinstance(net, BatchedEvaluator) or (isinstance(net, torch.nn.Module) and ev == getattr(net, "predict_batch", None))
 
     def _evaluator(self, ctx):
         net = self.neural_net
@@ -129,8 +136,17 @@ class MCTS:
         """boards int8 [G,R,C], players int8 [G] (device tensors) -> (pi float64 [G,A], ctx).
         noise: None or float64 [G,A] Dirichlet draws scattered to the legal actions."""
         ctx = self._context(boards.shape[0])
-        ctx.search(boards, players, self._evaluator(ctx), self.num_simulations, noise=noise,
-                   eps=self.dirichlet_epsilon, active=active)
+        ev = self._evaluator(ctx)
+        if self.use_graph and self._capturable(ev) and self.num_simulations > 8:
+            # device-resident evaluator: replay [forward + yy_mcts_step] from a hipGraph (one host call per simulation
+            # instead of one per kernel); same launches, same results as the eager loop
+            from .self_play import LockstepSearch
+            cached = getattr(ctx, "_lockstep", None)       # lives and dies with the context whose buffers it captured;
+            if cached is None or cached[0] is not self.neural_net:   # holds the network it captured alive
+                cached = ctx._lockstep = (self.neural_net, LockstepSearch(ctx, ev, use_graph=True))
+            cached[1].run(boards, players, self.num_simulations, noise=noise, eps=self.dirichlet_epsilon, active=active)
+        else:
+            ctx.search(boards, players, ev, self.num_simulations, noise=noise, eps=self.dirichlet_epsilon, active=active)
         if self.temperature in (0, 1.0):
             pi = ctx.root_policy(temperature_zero=(self.temperature == 0))
         else:
