@@ -15,6 +15,7 @@ Fixture families:
      search_net_8x8.npz    MCTS.search with the real seeded 128x10 net, evaluator outputs recorded
   G4 episodes.npz          SelfPlayWorker.play_game transcripts (literal and copied adapter)
   G6 augment.npz           DataProcessor.augment_sample: the 8 symmetric (planes, policy) variants
+  G7 ucb.npz               Node.select_child on random child statistics (ties, unvisited children, f32 / python-float sums)
 
 The reference imports create mcts.log / neural_network.log / training.log in the
 CWD, so run from a scratch directory.  Nothing is written into the reference tree.
@@ -511,6 +512,40 @@ def gen_g6():
     print("wrote", path, flush=True)
 
 
+def gen_ucb():
+    """G7 ucb.npz: Node.select_child (mcts.py:97-145) on random child statistics, with ties, unvisited children, python-float
+    and float32 value sums."""
+    _import_ref()
+    from src.yin_yang.ai.mcts import Node
+    rng = np.random.default_rng(77)
+    n, K = 4000, 12
+    out = dict(k=np.zeros(n, np.int32), visits=np.zeros((n, K), np.int32), wsum=np.zeros((n, K), np.float32),
+               w_is_f32=np.zeros((n, K), np.uint8), prior=np.zeros((n, K), np.float32), cpuct=np.zeros(n, np.float64),
+               chosen=np.zeros(n, np.int32))
+    for i in range(n):
+        k = int(rng.integers(1, K + 1))
+        node = Node(None)
+        cp = float(rng.choice([1.0, 0.5, 2.0, 1.25]))
+        coarse = rng.random() < 0.5                       # coarse grids make exact ties likely
+        for a in range(k):
+            ch = Node(None, parent=node, action=a, prior=np.float32(rng.integers(1, 9) / 16.0 if coarse else rng.random()))
+            ch.visits = int(rng.integers(0, 4 if coarse else 40))
+            if ch.visits:
+                w = rng.integers(-ch.visits, ch.visits + 1) / (2.0 if coarse else 1.0) * (1.0 if coarse else rng.random())
+                if rng.random() < 0.8:
+                    ch.value_sum = np.float32(w)
+                    out["w_is_f32"][i, a] = 1
+                else:
+                    ch.value_sum = float(np.float32(w))   # still a python float: only terminal values were added
+            node.children[a] = ch
+            out["visits"][i, a], out["wsum"][i, a], out["prior"][i, a] = ch.visits, ch.value_sum, ch.prior
+        a_sel, _ = node.select_child(cp)
+        out["k"][i], out["cpuct"][i], out["chosen"][i] = k, cp, a_sel
+    path = os.path.join(OUT, "ucb.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="g1,g2,g3,g3net,g4,g6")
@@ -533,6 +568,8 @@ def main():
         gen_g4(pool)
     if "g6" in only:
         gen_g6()
+    if "ucb" in only:
+        gen_ucb()
     if "edge" in only:      # degenerate and maximum geometries (1 x N, N x 1, 2 x 2, the 192-cell / 16-wide limits)
         gen_g1([(1, 1), (1, 6), (7, 1), (2, 2), (2, 9), (13, 14), (16, 12), (12, 16)], 256, pool)
         gen_g2([(1, 6), (7, 1), (16, 12)], 64)

@@ -12,6 +12,8 @@ an object with `predict(board) -> (policy[A], value)` (called once per evaluatio
 the reference does) or a callable batched evaluator `planes[G,5,R,C] -> (policy[G,A], value[G])`
 on the device (network.BatchedEvaluator), which is the fast path.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -37,6 +39,31 @@ class Node:
 
     def get_visit_count(self):
         return self.visits
+
+    def select_child(self, c_puct=1.0):
+        """PUCT choice over this node's children (mcts.py:97-145), evaluated on the host view with the same scalar types
+        the reference holds (np.float32 priors / value sums, python ints), hence the same float32 rounding: S = sum of the
+        CHILDREN's visits, q = W/N (0 when unvisited), u = c_puct * P * sqrt(S) / (1 + N), strict > so the lowest
+        action wins ties.  The device kernel does the same per level (csrc/yy_engine.hip, do_select)."""
+        total = sum(ch.visits for ch in self.children.values())
+        root_s = math.sqrt(total)
+        best, best_a, best_child = -float("inf"), -1, None
+        for a in sorted(self.children):
+            ch = self.children[a]
+            q = ch.value_sum / ch.visits if ch.visits > 0 else 0.0
+            score = q + c_puct * ch.prior * root_s / (1 + ch.visits)
+            if score > best:
+                best, best_a, best_child = score, a, ch
+        return best_a, best_child
+
+    def update(self, value):
+        """mcts.py:147-156: one visit, value added from this node's point of view (the caller flips the sign per ply)."""
+        self.visits += 1
+        self.value_sum += value
+
+    def get_children_distribution(self, temperature=1.0, action_size=None):
+        """mcts.py:183-215 on this node's children."""
+        return children_distribution(self.get_children_visit_counts(action_size), temperature)
 
     def get_children_visit_counts(self, action_size=None):
         n = action_size if action_size is not None else (max(self.children) + 1 if self.children else 0)
