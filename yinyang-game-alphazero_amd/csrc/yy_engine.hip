@@ -988,15 +988,15 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
         }
         c->bytes += a.n;
     }
-    HIP_TRY(hipMemset(c->state, 0, G * sizeof(GameState)));
-    HIP_TRY(hipMemset(c->nodes, 0, G * c->node_cap * sizeof(uint4)));
     // f32(math.sqrt(S)) table built with the host's correctly rounded double sqrt (mcts.py:130)
     float *tab = new float[cfg->max_sims + 2];
     for (int s = 0; s < cfg->max_sims + 2; s++) tab[s] = (float)sqrt((double)s);
-    hipError_t e = hipMemcpy(c->sqrt_tab, tab, (size_t)(cfg->max_sims + 2) * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = hipMemset(c->state, 0, G * sizeof(GameState));
+    if (e == hipSuccess) e = hipMemset(c->nodes, 0, G * c->node_cap * sizeof(uint4));
+    if (e == hipSuccess) e = hipMemcpy(c->sqrt_tab, tab, (size_t)(cfg->max_sims + 2) * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     delete[] tab;
-    if (e != hipSuccess) { yy_mcts_destroy(c); return set_err(YY_E_HIP, "hipMemcpy: %s%s", hipGetErrorString(e)); }
-    HIP_TRY(hipDeviceSynchronize());
+    if (e != hipSuccess) { yy_mcts_destroy(c); return set_err(YY_E_HIP, "arena initialisation: %s%s", hipGetErrorString(e)); }
     *out = c;
     return YY_OK;
 }
