@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 2 run TO COMPLETION: 8x8, 800 sims, 4096 concurrent games, frozen seeded 128x10 net, every
+game played to its end (~53 plies each).  Whole-run wall time includes the ragged tail (games end at
+different plies, the batch empties).  Also a 2x oversubscribed run (8192 games through 4096 slots) where finished
+slots are refilled, the way a production iteration keeps the batch full.
+    python tools/config2_full.py [--games 4096] [--nn bf16] [--out gpurun_out/config2_full.json]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import yinyang_game_alphazero_amd as pkg
+from yinyang_game_alphazero_amd.self_play import SelfPlayEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--games", type=int, default=4096)
+ap.add_argument("--slots", type=int, default=4096)
+ap.add_argument("--sims", type=int, default=800)
+ap.add_argument("--nn", default="bf16")
+ap.add_argument("--out", default="gpurun_out/config2_full.json")
+a = ap.parse_args()
+torch.manual_seed(0)
+game = pkg.YinYangGame(8, 8)
+net = pkg.YinYangNeuralNetwork(game).cuda().eval()
+ev = pkg.BatchedEvaluator(net, a.nn)
+res = []
+for total in (a.games, 2 * a.games):
+    eng = SelfPlayEngine(game, ev, num_simulations=a.sims, concurrent_games=a.slots, seed=1000)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    last = [t0]
+
+    def progress(e):
+        if time.perf_counter() - last[0] > 30:
+            last[0] = time.perf_counter()
+            print("[config2] %d games, %.0f s, %d slots alive" % (total, last[0] - t0, int(e.alive.sum())), flush=True)
+    ex = eng.run(total, progress=progress)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    c = eng.ctx.status()
+    n = int(ex["values"].shape[0])
+    plies = torch.bincount(ex["game_id"] - ex["game_id"].min()).float()
+    r = dict(games=total, slots=a.slots, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
+             expansions=int(c["evals"]), expansions_per_s=c["evals"] / dt, plies_mean=float(plies.mean()),
+             plies_min=int(plies.min()), plies_max=int(plies.max()),
+             z_counts={str(v): int((ex["values"] == v).sum()) for v in (1.0, -1.0)} | {"draw": int((ex["values"].abs() < 0.5).sum())})
+    print(json.dumps(r), flush=True)
+    res.append(r)
+    eng.close()
+os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+json.dump(dict(device=torch.cuda.get_device_name(0), runs=res), open(a.out, "w"), indent=1)
