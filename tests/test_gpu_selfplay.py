@@ -179,7 +179,9 @@ def test_game_api_matches_oracle(pkg):
     assert game.getBoardSize() == (5, 7) and game.getActionSize() == 35 and game._action_to_coords(17) == (2, 3)
 
 
-def test_engine_full_games_properties(pkg):
+@pytest.mark.parametrize("use_graph,row_tiers", [(False, ()), (False, (8, 16, 32, 64)), (True, (8, 16, 32, 64))],
+                         ids=["full_rows", "packed_tail", "packed_tail_graph"])
+def test_engine_full_games_properties(pkg, use_graph, row_tiers):
     """SelfPlayEngine, 96 concurrent 6x6 games to completion, device RNG.  Size-independent properties:
     every example state is reachable (stone counts differ by <= 1 + passes... here: legal position with
     no monochrome 2x2 and both colours connected), pi sums to 1 and is supported on legal moves, labels are
@@ -191,9 +193,12 @@ def test_engine_full_games_properties(pkg):
         G = planes.shape[0]
         return torch.full((G, 36), 1.0 / 36, device=planes.device), torch.zeros(G, device=planes.device)
 
-    eng = pkg.SelfPlayEngine(game, ev, num_simulations=24, concurrent_games=96, seed=5, use_graph=False)
+    eng = pkg.SelfPlayEngine(game, ev, num_simulations=24, concurrent_games=96, seed=5, use_graph=use_graph,
+                             row_tiers=row_tiers)
     ex = eng.run(150)
     assert eng.games_finished == 150
+    if row_tiers:       # the draining batch was packed to the front and evaluated on fewer rows
+        assert eng.rows < 96 and (not use_graph or len(eng.search.graphs) >= 2)
     st, pi, z, gid, ply = (ex[k].cpu().numpy() for k in ("states", "policies", "values", "game_id", "ply"))
     assert st.shape[0] == pi.shape[0] == z.shape[0] > 150 * 10
     assert np.allclose(pi.sum(1), 1.0, atol=1e-6)
@@ -207,6 +212,19 @@ def test_engine_full_games_properties(pkg):
     for g in np.unique(gid)[:40]:
         sel = gid == g
         assert sorted(ply[sel].tolist()) == list(range(int(sel.sum())))
+    # every game is a legal trajectory: consecutive recorded states differ by exactly one stone, placed on a cell the
+    # oracle calls legal for its colour (passes record nothing, so the mover is read off the new stone)
+    for g in np.unique(gid)[:60]:
+        sel = np.flatnonzero(gid == g)
+        sel = sel[np.argsort(ply[sel])]
+        assert not st[sel[0]].any()
+        for a, b in zip(sel[:-1], sel[1:]):
+            d = st[b].astype(np.int32) - st[a].astype(np.int32)
+            cells = np.flatnonzero(d.reshape(-1))
+            assert len(cells) == 1 and abs(int(d.reshape(-1)[cells[0]])) == 1 and st[a].reshape(-1)[cells[0]] == 0
+            colour = int(d.reshape(-1)[cells[0]])
+            assert O.valid_mask(st[a][None], colour)[0][cells[0]] == 1
+            assert pi[a][cells[0]] > 0
     # no finished position contains a monochrome 2x2 block
     s = st.astype(np.int32)
     blk = (s[:, :-1, :-1] == s[:, 1:, :-1]) & (s[:, :-1, :-1] == s[:, :-1, 1:]) & (s[:, :-1, :-1] == s[:, 1:, 1:]) & (s[:, :-1, :-1] != 0)

@@ -39,41 +39,72 @@ class LockstepSearch:
     def __init__(self, ctx, evaluator, use_graph=True, eager_sims=3):
         self.ctx, self.evaluator, self.use_graph = ctx, evaluator, use_graph
         self.eager_sims = eager_sims
-        self.graph = None
+        self.graphs = {}       # evaluated rows -> captured step
         self.timer = None      # optional object with start()/stop() bracketing every tree-kernel launch (bench.py)
+        self._policy = self._value = None
 
-    def _sim_step(self):
-        policy, value = self.evaluator(self.ctx.planes)
+    @property
+    def graph(self):
+        return self.graphs.get(self.ctx.G)
+
+    @graph.setter
+    def graph(self, g):
+        if g is None:
+            self.graphs.clear()
+        else:
+            self.graphs[self.ctx.G] = g
+
+    def _evaluate(self, rows):
+        """Evaluator on the first `rows` leaf rows (all searching games must sit there); returns full-height buffers."""
+        ctx = self.ctx
+        if rows >= ctx.G:
+            return self.evaluator(ctx.planes)
+        policy, value = self.evaluator(ctx.planes[:rows])
+        if self._policy is None:
+            self._policy = torch.zeros((ctx.G, policy.shape[1]), dtype=torch.float32, device=ctx.device)
+            self._value = torch.zeros(ctx.G, dtype=torch.float32, device=ctx.device)
+        self._policy[:rows].copy_(policy)
+        self._value[:rows].copy_(value)
+        return self._policy, self._value
+
+    def _sim_step(self, rows):
+        policy, value = self._evaluate(rows)
         if self.timer is not None:
             self.timer.start()
         self.ctx.step(policy, value)
         if self.timer is not None:
             self.timer.stop()
 
-    def run(self, boards, root_players, num_sims, noise=None, eps=0.25, active=None):
+    def run(self, boards, root_players, num_sims, noise=None, eps=0.25, active=None, rows=None):
+        """rows: evaluate only leaf rows [0, rows) -- the caller guarantees every active game has an index below it
+        (SelfPlayEngine packs the live games to the front when a batch drains).  One graph per distinct `rows`."""
         ctx = self.ctx
+        rows = ctx.G if rows is None else min(int(rows), ctx.G)
         ctx.begin(boards, root_players, active)
-        policy, _ = self.evaluator(ctx.planes)                 # mcts.py:295, value discarded
+        policy, _ = self._evaluate(rows)                       # mcts.py:295, value discarded
         ctx.expand_root(policy, noise, eps)
         ctx.select()
         done = 0
         n_fused = num_sims - 1
-        if self.use_graph and self.graph is None and n_fused > self.eager_sims:
+        graph = self.graphs.get(rows)
+        if self.use_graph and graph is None and n_fused > self.eager_sims:
             for _ in range(self.eager_sims):                   # warm-up (MIOpen algo search etc.) = real sims
-                self._sim_step()
+                self._sim_step(rows)
                 done += 1
             torch.cuda.synchronize(ctx.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._sim_step()
-            self.graph = g
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._sim_step(rows)
+            self.graphs[rows] = graph
+        if not self.use_graph:
+            graph = None
         while done < n_fused:
-            if self.graph is not None:
-                self.graph.replay()
+            if graph is not None:
+                graph.replay()
             else:
-                self._sim_step()
+                self._sim_step(rows)
             done += 1
-        policy, value = self.evaluator(ctx.planes)             # last simulation: no further select
+        policy, value = self._evaluate(rows)                   # last simulation: no further select
         ctx.expand_backup(policy, value)
 
 
@@ -82,7 +113,7 @@ class SelfPlayEngine:
     def __init__(self, game, evaluator, num_simulations=800, concurrent_games=4096, cpuct=1.0,
                  dirichlet_alpha=0.3, dirichlet_epsilon=0.25, temperature_threshold=10,
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
-                 device=None, first_game_index=0, game_index_stride=1):
+                 device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None):
         assert board_semantics in ("aliased", "copied")
         self.game = game
         self.R, self.C = game.getBoardSize()
@@ -121,6 +152,18 @@ class SelfPlayEngine:
         self.games_target = 0
         self.positions = 0
         self._ar = torch.arange(G, device=dev)
+        # draining batch: once no new game will start, live games are packed to the front and only the first `rows`
+        # leaf rows are evaluated (rows = the smallest tier that holds them; one captured step per tier)
+        self.compact_tail = bool(compact_tail)
+        self.rows = G
+        self.tiers = sorted({G} | ({m for m in range(1024, G, 1024)} | {m for m in (512, 256) if m < G}
+                                   if row_tiers is None else {int(t) for t in row_tiers if 0 < int(t) < G}))
+
+    def _pack_live_games(self):
+        """Once per tier change: stable permutation of every per-slot tensor, live games first."""
+        perm = torch.argsort((~self.alive).to(torch.int8), stable=True)
+        for name in ("boards", "players", "ply", "n_ex", "alive", "game_id", "hist_state", "hist_pi", "hist_player"):
+            setattr(self, name, getattr(self, name).index_select(0, perm).contiguous())
 
     # ---- slots
     def _start_games(self, slots):
@@ -129,6 +172,7 @@ class SelfPlayEngine:
             return
         ids = self.first_game_index + (self.games_started + torch.arange(n, device=self.device)) * self.stride
         self.games_started += n
+        self.rows = self.G                            # new games may sit anywhere
         self.boards[slots] = 0
         self.players[slots] = 1                       # black starts (self_play.py:81)
         self.ply[slots] = 0
@@ -165,6 +209,12 @@ class SelfPlayEngine:
     # ---- one lockstep move for every live game (self_play.py:91-192)
     def play_move(self):
         dev, G = self.device, self.G
+        if self.compact_tail and self.games_started >= self.games_target:      # the batch is draining
+            n_live = int(self.alive.sum())
+            need = next(t for t in self.tiers if t >= n_live)
+            if need < self.rows:
+                self._pack_live_games()
+                self.rows = need
         ones = torch.ones(G, dtype=torch.int8, device=dev)
         pending = self.alive.clone()
         searching = torch.zeros(G, dtype=torch.bool, device=dev)
@@ -198,7 +248,7 @@ class SelfPlayEngine:
                                         generator=self.gen) * mask
             noise = torch.where(first[:, None], gam / gam.sum(1, keepdim=True).clamp_min(1e-300), torch.zeros_like(gam))
             noise = noise.contiguous()
-        self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=active)
+        self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=active, rows=self.rows)
         pi = self.ctx.root_policy()                                            # T == 1 distribution, :329
         # ---- record the example before the move (:140)
         slot = self.n_ex.clamp_max(self.T - 1)
