@@ -15,14 +15,16 @@ ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--slots", type=int, default=4096)
 ap.add_argument("--sims", type=int, default=800)
 ap.add_argument("--nn", default="bf16")
+ap.add_argument("--rows", type=int, default=8)
+ap.add_argument("--single", action="store_true", help="only the plain run (no 2x refilled run)")
 ap.add_argument("--out", default="gpurun_out/config2_full.json")
 a = ap.parse_args()
 torch.manual_seed(0)
-game = pkg.YinYangGame(8, 8)
+game = pkg.YinYangGame(a.rows, a.rows)
 net = pkg.YinYangNeuralNetwork(game).cuda().eval()
 ev = pkg.BatchedEvaluator(net, a.nn)
 res = []
-for total in (a.games, 2 * a.games):
+for total in ((a.games,) if a.single else (a.games, 2 * a.games)):
     eng = SelfPlayEngine(game, ev, num_simulations=a.sims, concurrent_games=a.slots, seed=1000)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     last = [t0]
@@ -36,7 +38,7 @@ for total in (a.games, 2 * a.games):
     c = eng.ctx.status()
     n = int(ex["values"].shape[0])
     plies = torch.bincount(ex["game_id"] - ex["game_id"].min()).float()
-    r = dict(games=total, slots=a.slots, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
+    r = dict(board=f"{a.rows}x{a.rows}", games=total, slots=a.slots, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
              expansions=int(c["evals"]), expansions_per_s=c["evals"] / dt, plies_mean=float(plies.mean()),
              plies_min=int(plies.min()), plies_max=int(plies.max()),
              z_counts={str(v): int((ex["values"] == v).sum()) for v in (1.0, -1.0)} | {"draw": int((ex["values"].abs() < 0.5).sum())})
