@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank control flow with several ranks sharing ONE GPU (RCCL needs a "
+                         "device per rank); the exchange then goes through host memory")
     return ap.parse_args()
 
 
@@ -232,11 +235,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
+    if args.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torchrun the RCCL path is exercised even at N=1
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout is reserved for the
+        # one JSON line, so park fd 1 on stderr while the communicator is created (eager with device_id) and exercised once
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                dist.barrier()
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo")
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     import yinyang_game_alphazero_amd as pkg
     from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, gather_examples
 
@@ -250,6 +270,8 @@ def main():
                          use_graph=not args.no_graph, seed=1000 + rank, device=dev,
                          first_game_index=rank, game_index_stride=world)
     stagger_start(eng, 4242 + rank)
+
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collectives run
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,10 +294,10 @@ def main():
     ex = eng.collect()
     # the single exchange of the path: all-gather the examples produced in the timed region
     tg0 = time.perf_counter()
-    ex_all = gather_examples(ex)
+    ex_all = gather_examples(ex if cdev == dev else {k: v.to(cdev) for k, v in ex.items()})
     torch.cuda.synchronize()
     gather_s = time.perf_counter() - tg0
-    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=cdev)
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
