@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=8)
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32", "fp32t"])
+    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32", "fp32t", "bf16x3"])
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -155,12 +155,13 @@ def roofline_pass(eng):
     # the tower kernel alone (HIP events on its launch stream), when the evaluator uses it
     tower_ms = None
     ev = eng.evaluator
-    if getattr(ev, "mode", "") == "fp32t":
+    if getattr(ev, "mode", "") in ("fp32t", "bf16x3"):
         from yinyang_game_alphazero_amd import engine as E
+        tower = E.tower_forward_f32 if ev.mode == "fp32t" else E.tower_forward_x3
         tt = HipEventTimer(5)
         for _ in range(5):
             tt.start()
-            E.tower_forward_f32(eng.ctx.planes, ev.f32_w, ev.f32_b, ev.f32_layers)
+            tower(eng.ctx.planes, ev.f32_w, ev.f32_b, ev.f32_layers)
             tt.stop()
         tower_ms, _ = tt.mean_ms()
     if getattr(ev, "tower", False):
@@ -332,8 +333,14 @@ def main():
             if f32t:   # exact-f32 kernel: K of the stem padded to 8, no fused heads
                 tower_flops = (2 * 9 * 8 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)) * args.games
                 ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            peak = MFMA_F32_PEAK_TFLOPS if f32t else MFMA_BF16_PEAK_TFLOPS
+            x3 = args.nn == "bf16x3"
+            if x3:     # split-bf16 kernel: K of the stem padded to 16, no fused heads
+                tower_flops = (2 * 9 * 16 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)) * args.games
+                ach = tower_flops / (tower_ms * 1e-3) / 1e12
+            # split-bf16 issues three bf16 MFMAs per algorithmic multiply-add: its bound is a third of the bf16 peak
+            peak = MFMA_F32_PEAK_TFLOPS if f32t else (MFMA_BF16_PEAK_TFLOPS / 3 if x3 else MFMA_BF16_PEAK_TFLOPS)
             name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
+                "k_tower_x3 (stem + residual tower, split-bf16: 3 bf16 MFMAs per product term, f32-grade accuracy; peak = bf16 MFMA peak / 3)" if x3 else \
                 {6: "k_towerq<6,8>", 8: "k_tower" if args.games > 512 else "k_towerq<8,%d>" % (1 if args.games <= 256 else 2), 12: "k_tower12"}.get(args.rows, "k_tower") + \
                 " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
             ttraffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same G, same kernel)

@@ -198,6 +198,14 @@ int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float
 int yy_nn_tower_f32(const float *planes, const void *weights, const float *bias, float *out, int G,
                     int R, int C, int channels, int n_layers, yy_stream_t stream);
 
+/* The residual tower at float32-grade accuracy on the BF16 matrix cores: activations and weights are (hi, lo) bf16
+ * pairs (16 mantissa bits), each product is w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on v_mfma_f32_32x32x16_bf16 into one f32
+ * accumulator; bias / residual / ReLU in f32.  Same I/O as yy_nn_tower_f32; weights = bf16 chunks
+ * [9 + 36*(n_layers-1)][8192] from network.pack_tower_x3.  8x8 boards, 128 channels.  Replaces the same reference
+ * code as yy_nn_tower_f32 (neural_network.py:94-110). */
+int yy_nn_tower_bf16x3(const float *planes, const void *weights, const float *bias, float *out, int G,
+                       int R, int C, int channels, int n_layers, yy_stream_t stream);
+
 /* Head finish (neural_network.py:115, 120-121, 152): h bf16 [G, A+H] = policy logits then value_fc1
  * outputs (bias added); policy float32 [G,A] = softmax(logits); value float32 [G] =
  * tanh(relu(hidden) . w2 + b2) with w2 float32 [H], b2 float32 [1]. */

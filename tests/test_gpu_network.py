@@ -229,6 +229,45 @@ def test_f32_tower_kernel_matches_fp32_module():
         assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4
 
 
+def test_split_bf16_tower_kernel_matches_fp32_module():
+    """csrc/yy_tower_x3.hip (activations and weights as (hi, lo) bf16 pairs, three bf16 MFMAs per product term, f32
+    accumulation) against the fp32 nn.Module: 16 mantissa bits per operand, so activations within 1e-4 relative to the layer
+    scale (measured ~1e-5), policy 1e-5 / value 1e-4 abs -- the same bounds as the exact-f32 kernel."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.manual_seed(2)
+    torch.backends.cudnn.allow_tf32 = False
+    game = pkg.YinYangGame(8, 8)
+    rng = np.random.default_rng(6)
+    for blocks, G in ((1, 3), (10, 71)):
+        net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.1)
+                if isinstance(m, torch.nn.Conv2d):
+                    m.bias.normal_(0, 0.05)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        ev = pkg.BatchedEvaluator(net, "bf16x3")
+        x_t = pkg.engine.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers)
+        with torch.no_grad():
+            x = torch.relu(net.bn1(net.conv1(planes)))
+            for blk in net.res_blocks:
+                x = blk(x)
+        scale = float(x.abs().max())
+        err = float((x_t - x).abs().max())
+        print("bf16x3 tower: blocks %d max|err| %.3e scale %.3e" % (blocks, err, scale))
+        assert err <= 1e-4 * scale, (blocks, err, scale)
+        p, v = ev(planes)
+        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+        print("bf16x3 evaluator: policy err %.3e value err %.3e" % (float((p - p32).abs().max()), float((v - v32).abs().max())))
+        assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4
+
+
 def test_gpu_evaluators_against_reference_recorded_outputs():
     """The reference's own (board -> policy, value) pairs (search_net_8x8.npz, CPU fp32, seed 0) against the mirror on the
     GPU: fp32 module and the exact-f32 tower within 1e-5 on policy / 1e-4 on value; bf16 tower within 2e-2 / 5e-2."""
@@ -242,6 +281,6 @@ def test_gpu_evaluators_against_reference_recorded_outputs():
     boards = torch.from_numpy(z["rec_boards"][1, :n]).cuda()
     rp, rv = torch.from_numpy(z["rec_policy"][1, :n]).cuda(), torch.from_numpy(z["rec_value"][1, :n]).cuda()
     planes = pkg.engine.encode_planes(boards)
-    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
+    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
         p, v = pkg.BatchedEvaluator(net, mode)(planes)
         assert float((p - rp).abs().max()) < tp and float((v - rv).abs().max()) < tv, mode

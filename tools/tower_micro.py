@@ -7,12 +7,16 @@ import yinyang_game_alphazero_amd as pkg
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 HEADS = len(sys.argv) > 3 and sys.argv[3] == "heads"      # the shipped variant: tower + fused 1x1 head convs
+X3 = len(sys.argv) > 3 and sys.argv[3] == "x3"            # split-bf16 tower (f32-grade accuracy)
 torch.manual_seed(0)
 net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
 ev = pkg.BatchedEvaluator(net, "bf16")
 rng = np.random.default_rng(0)
 planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
+evx = pkg.BatchedEvaluator(net, "bf16x3") if X3 else None
 def launch():
+    if X3:
+        return pkg.engine.tower_forward_x3(planes, evx.f32_w, evx.f32_b, evx.f32_layers)
     if HEADS:
         return pkg.engine.tower_heads_forward(planes, ev.towerh_w, ev.towerh_b, ev.tower_layers)
     return pkg.engine.tower_forward(planes, ev.tower_w, ev.tower_b, ev.tower_layers)

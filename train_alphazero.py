@@ -40,7 +40,8 @@ def parse_args(argv=None):
     p.add_argument("--concurrent-games", type=int, default=4096)
     p.add_argument("--board-semantics", choices=["copied", "aliased"], default="copied")
     p.add_argument("--reference-quirks", action="store_true", help="reproduce Q4/Q5 of the reference's play_game")
-    p.add_argument("--nn", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--nn", choices=["bf16", "fp32", "fp32t", "bf16x3"], default="bf16",
+                   help="evaluator: bf16 tower (default), fp32 module, exact-f32 tower, split-bf16 tower (f32-grade accuracy)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--arena-games", type=int, default=40)
     p.add_argument("--channels", type=int, default=128)

@@ -163,6 +163,19 @@ def tower_forward_f32(planes, weights, bias, n_layers):
     return out.permute(0, 3, 1, 2)
 
 
+def tower_forward_x3(planes, weights, bias, n_layers):
+    """Stem + residual tower at float32-grade accuracy on the bf16 MFMA (split-bf16, csrc/yy_tower_x3.hip).
+    planes f32 [G,5,8,8] -> f32 activations as a channels-last tensor [G,128,8,8]."""
+    G = planes.shape[0]
+    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "split-bf16 tower weights")
+    _need(bias, torch.float32, (n_layers, 128), "tower bias")
+    out = torch.empty((G, 8, 8, 128), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_bf16x3(_p(planes), _p(weights), _p(bias), _p(out), G, 8, 8, 128, n_layers, _stream()))
+    return out.permute(0, 3, 1, 2)
+
+
 def tower_heads_forward(planes, weights, bias, n_layers):
     """Tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] (R = 8 or 12) ->
     bf16 [G,2,32*R*R] = (policy features, value features) in the reference's flatten order."""

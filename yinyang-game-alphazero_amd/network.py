@@ -176,6 +176,34 @@ def pack_tower_f32(net):
     return torch.stack(chunks).contiguous(), torch.stack(biases).contiguous()
 
 
+def pack_tower_x3(net):
+    """Split-bf16 packing for csrc/yy_tower_x3.hip: every folded float32 weight w becomes hi = bf16(w), lo = bf16(w - hi);
+    chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] bf16 with cout = nt*32 + c and
+    cin = quarter*32 + ks*16 + h*8 + j (part 0 = hi, 1 = lo); the stem has one chunk per tap (5 planes padded to 16
+    channels, ks = 0 only), every other layer 36 (tap-major, then quarter).  Returns int16 [n_chunks, 8192], float32 bias."""
+    convs = [(net.conv1, net.bn1)]
+    for blk in net.res_blocks:
+        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    chunks, biases = [], []
+    for li, (conv, bn) in enumerate(convs):
+        w, b = fold_batchnorm(conv, bn)
+        w = w.float().cpu()
+        wp = torch.zeros((128, 128, 3, 3))
+        wp[:, :w.shape[1]] = w
+        hi = wp.to(torch.bfloat16)
+        lo = (wp - hi.float()).to(torch.bfloat16)
+        for tap in range(9):
+            parts = []
+            for t in (hi, lo):
+                t = t[:, :, tap // 3, tap % 3].reshape(4, 32, 4, 2, 2, 8)         # nt, c, quarter, ks, h, j
+                parts.append(t.permute(2, 3, 0, 4, 1, 5))                          # quarter, ks, nt, h, c, j
+            both = torch.stack(parts, dim=2).contiguous()                          # quarter, ks, part, nt, h, c, j
+            for quarter in range(1 if li == 0 else 4):
+                chunks.append(both[quarter].reshape(-1))
+        biases.append(b.float().cpu())
+    return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
+
+
 def pack_heads(net):
     """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
     [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
@@ -195,6 +223,9 @@ class BatchedEvaluator:
     mode "fp32": the module as is (parity path: same arithmetic as predict()).
     mode "fp32t": the same float32 weights, but the stem + residual tower run in the hand-written exact-f32 MFMA kernel
     (csrc/yy_tower_f32.hip; 8x8 boards, 128 channels); heads by torch in float32.  Differs from "fp32" only by summation order.
+    mode "bf16x3": float32-grade accuracy on the bf16 matrix cores (csrc/yy_tower_x3.hip): activations and weights as
+    (hi, lo) bf16 pairs, three MFMAs per product term, f32 accumulation / bias / residual; heads by torch in float32.  Agrees
+    with "fp32" to ~1e-5 on the policy at about a third of the "fp32t" cost.
     mode "bf16"/"fp16": inference-only fast path -- eval-mode BatchNorm folded into the convs,
     channels-last activations, reduced-precision MFMA convolutions (MIOpen implicit GEMM), softmax/tanh
     in fp32.  In bf16 mode with `fused_epilogue` (default) every convolution is issued WITHOUT bias and
@@ -211,10 +242,10 @@ class BatchedEvaluator:
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
                       and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
-        if mode == "fp32t":
+        if mode in ("fp32t", "bf16x3"):
             if tuple(net.board_size) != (8, 8) or net.conv1.out_channels != 128 or len(net.res_blocks) > 11:
-                raise ValueError("fp32t needs 8x8 boards, 128 channels, at most 11 residual blocks")
-            wq, bq = pack_tower_f32(net)
+                raise ValueError(mode + " needs 8x8 boards, 128 channels, at most 11 residual blocks")
+            wq, bq = pack_tower_f32(net) if mode == "fp32t" else pack_tower_x3(net)
             self.f32_w, self.f32_b = wq.to(self.device), bq.to(self.device)
             self.f32_layers = 1 + 2 * len(net.res_blocks)
             self.f32_heads = (fold_batchnorm(net.policy_conv, net.policy_bn), fold_batchnorm(net.value_conv, net.value_bn))
@@ -274,10 +305,11 @@ class BatchedEvaluator:
     def __call__(self, planes):
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
-        if self.mode == "fp32t":
+        if self.mode in ("fp32t", "bf16x3"):
             from . import engine
             n = self.net
-            x = engine.tower_forward_f32(planes, self.f32_w, self.f32_b, self.f32_layers)
+            tower = engine.tower_forward_f32 if self.mode == "fp32t" else engine.tower_forward_x3
+            x = tower(planes, self.f32_w, self.f32_b, self.f32_layers)
             (pw, pb), (vw, vb) = self.f32_heads
             p = F.relu(F.conv2d(x, pw, pb)).contiguous().flatten(1)
             v = F.relu(F.conv2d(x, vw, vb)).contiguous().flatten(1)
