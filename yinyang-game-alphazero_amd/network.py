@@ -248,7 +248,20 @@ class BatchedEvaluator:
             wq, bq = pack_tower_f32(net) if mode == "fp32t" else pack_tower_x3(net)
             self.f32_w, self.f32_b = wq.to(self.device), bq.to(self.device)
             self.f32_layers = 1 + 2 * len(net.res_blocks)
-            self.f32_heads = (fold_batchnorm(net.policy_conv, net.policy_bn), fold_batchnorm(net.value_conv, net.value_bn))
+            # float32 heads in four GEMM-shaped steps: both 1x1 head convs as ONE [G*64,128] x [128,64] product, then
+            # policy_fc and value_fc1 as ONE product over [policy features | value features] (block weights)
+            (pw, pb), (vw, vb) = fold_batchnorm(net.policy_conv, net.policy_bn), fold_batchnorm(net.value_conv, net.value_bn)
+            self.hconv_w = torch.cat([pw, vw]).float().reshape(pw.shape[0] + vw.shape[0], -1).t().contiguous().to(self.device)
+            self.hconv_b = torch.cat([pb, vb]).float().contiguous().to(self.device)
+            A, F_, Hd = net.policy_fc.out_features, net.policy_fc.in_features, net.value_fc1.out_features
+            wc = torch.zeros((A + Hd, 2 * F_), dtype=torch.float32, device=self.device)
+            wc[:A, :F_] = net.policy_fc.weight.detach()
+            wc[A:, F_:] = net.value_fc1.weight.detach()
+            self.fc_cat_w = wc.contiguous()
+            self.fc_cat_b = torch.cat([net.policy_fc.bias.detach(), net.value_fc1.bias.detach()]).float().contiguous()
+            self.fc2_w = net.value_fc2.weight.detach().float().reshape(-1, 1).contiguous()
+            self.fc2_b = net.value_fc2.bias.detach().float().reshape(1).contiguous()
+            self.n_actions = A
             self.tower = False
             return
         if mode != "fp32":
@@ -309,13 +322,15 @@ class BatchedEvaluator:
             from . import engine
             n = self.net
             tower = engine.tower_forward_f32 if self.mode == "fp32t" else engine.tower_forward_x3
-            x = tower(planes, self.f32_w, self.f32_b, self.f32_layers)
-            (pw, pb), (vw, vb) = self.f32_heads
-            p = F.relu(F.conv2d(x, pw, pb)).contiguous().flatten(1)
-            v = F.relu(F.conv2d(x, vw, vb)).contiguous().flatten(1)
-            logits = n.policy_fc(p)
-            value = torch.tanh(n.value_fc2(F.relu(n.value_fc1(v)))).reshape(-1)
-            return F.softmax(logits, dim=1), value
+            x = tower(planes, self.f32_w, self.f32_b, self.f32_layers)           # NCHW view of [G,8,8,128] memory
+            G = x.shape[0]
+            cells = x.shape[2] * x.shape[3]
+            hc = torch.addmm(self.hconv_b, x.permute(0, 2, 3, 1).reshape(G * cells, -1), self.hconv_w)   # [G*cells, 64]
+            feats = torch.relu_(hc).view(G, cells, -1).transpose(1, 2).reshape(G, -1)     # [G, (head, ch, cell)] = NCHW flatten
+            h = torch.addmm(self.fc_cat_b, feats, self.fc_cat_w.t())                      # [G, A + 256]
+            A = self.n_actions
+            value = torch.tanh(torch.addmm(self.fc2_b, torch.relu(h[:, A:]), self.fc2_w)).reshape(-1)
+            return F.softmax(h[:, :A], dim=1), value
         if self.tower and self.fused_heads:
             from . import engine
             feats = engine.tower_heads_forward(planes, self.towerh_w, self.towerh_b, self.tower_layers)
