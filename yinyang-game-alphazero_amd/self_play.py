@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import engine
-from .game import YinYangGame, YinYangLogic
+from .game import YinYangLogic
 from .mcts import MCTS
 from .network import BatchedEvaluator, YinYangNeuralNetwork
 
