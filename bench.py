@@ -341,7 +341,7 @@ def main():
             peak = MFMA_F32_PEAK_TFLOPS if f32t else (MFMA_BF16_PEAK_TFLOPS / 3 if x3 else MFMA_BF16_PEAK_TFLOPS)
             name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
                 "k_tower_x3 (stem + residual tower, split-bf16: 3 bf16 MFMAs per product term, f32-grade accuracy; peak = bf16 MFMA peak / 3)" if x3 else \
-                {6: "k_towerq<6,8>", 8: "k_tower" if args.games > 512 else "k_towerq<8,%d>" % (1 if args.games <= 256 else 2), 12: "k_tower12"}.get(args.rows, "k_tower") + \
+                {6: "k_towerq<6,8>", 8: "k_tower" if args.games > 512 else "k_towerq<8,%d>" % (1 if args.games <= 256 else 2), 12: "k_towerq<12,2>"}.get(args.rows, "k_tower") + \
                 " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
             ttraffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same G, same kernel)
             tpmc = os.path.join(ROOT, "profiles", "r01_k_tower_hbm_pmc.json")

@@ -147,7 +147,7 @@ def test_tower_small_batch_kernels_bit_identical_to_main():
 
 @pytest.mark.parametrize("R", [12, 6])
 def test_tower_other_sizes_match_torch_bf16_path(R):
-    """12x12 (csrc/yy_tower12.hip) and 6x6 (csrc/yy_tower6.hip) variants: same checks as the 8x8 kernel -- tower activations within 2 bf16 ulps of
+    """12x12 and 6x6 (csrc/yy_towerq.hip <12,2> and <6,8>) variants: same checks as the 8x8 kernel -- tower activations within 2 bf16 ulps of
     scale per layer against torch bf16 convolutions on the same folded weights, fused head features within 2 ulps,
     end-to-end policy 2e-2 / value 5e-2 abs against the torch bf16 path and the fp32 module."""
     import torch

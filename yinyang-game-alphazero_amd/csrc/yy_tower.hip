@@ -343,11 +343,11 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
 
 // weights: bf16 chunks [9 + 18*(n_layers-1) (+1 head chunk)][8192] in fragment order (network.pack_tower);
 // bias f32 [n_layers (+1)][128]; planes f32 [G,5,8,8]; out bf16 [G,8,8,128] or out_heads bf16 [G,2,32,64].
-extern "C" int yy_tower12_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
-                                 int G, int n_layers, yy_stream_t s);   // yy_tower12.hip: 12x12 boards
-
 extern "C" int yy_tower6_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
                                 int G, int n_layers, yy_stream_t s);   // yy_towerq.hip: 6x6 boards
+
+extern "C" int yy_tower12q_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
+                                  int G, int n_layers, yy_stream_t s);   // yy_towerq.hip: 12x12, wave = cout quarter
 
 extern "C" int yy_tower8q_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
                                  int G, int n_layers, int tb, yy_stream_t s);   // yy_towerq.hip: 8x8, 1 or 2 boards per workgroup
@@ -360,7 +360,7 @@ static int launch_tower(const float *planes, const void *weights, const float *b
     const bool b8 = (R == 8 && C == 8), b12 = (R == 12 && C == 12), b6 = (R == 6 && C == 6);
     if (!(b8 || b12 || b6) || channels != TW_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > TW_MAX_LAYERS || (n_layers & 1) == 0)
         return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
-    if (b12) return yy_tower12_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
+    if (b12) return yy_tower12q_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     if (b6) return yy_tower6_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
     static const int force_tb = getenv("YY_TOWER_TB") ? atoi(getenv("YY_TOWER_TB")) : 0;     // timing experiments only

@@ -9,6 +9,7 @@
 // Instantiations:
 //   <6, 8>  6x6 boards: 8 boards = 288 columns = 9 tiles; 9 accumulators (144 registers) + packed residual (72);
 //           LDS 288 rows x 272 B (76.5 KB) + 4-slot x 16 KB ring + bias + zero row = 152 KB.  The 6x6 evaluator.
+//   <12, 2> 12x12 boards: two boards = 288 columns = 9 full tiles, the same shape as <6, 8>.  The 12x12 evaluator.
 //   <8, 1>  8x8 boards, ONE board per workgroup (2 tiles): the low-latency form for small batches (arena matches,
 //   <8, 2>  single-board MCTS.search, a few hundred concurrent games), where yy_tower.hip's 4-boards-per-workgroup
 //           grid leaves most CUs idle and a step costs one full workgroup latency whatever G is.  A quarter of the MFMA
@@ -316,6 +317,12 @@ static int launch_q(const float *planes, const void *weights, const float *bias,
 extern "C" int yy_tower6_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
                                 int G, int n_layers, yy_stream_t s) {
     return launch_q<6, 8>(planes, weights, bias, out, out_heads, G, n_layers, s);
+}
+
+// 12x12 boards: two boards = 288 columns = nine full tiles
+extern "C" int yy_tower12q_launch(const float *planes, const void *weights, const float *bias, void *out, void *out_heads,
+                                  int G, int n_layers, yy_stream_t s) {
+    return launch_q<12, 2>(planes, weights, bias, out, out_heads, G, n_layers, s);
 }
 
 // 8x8 boards, tb = 1 or 2 boards per workgroup (small batches; yy_tower.hip picks)

@@ -137,7 +137,7 @@ def bias_act_(x, bias, residual=None, relu=True):
 
 
 def tower_forward(planes, weights, bias, n_layers):
-    """Stem + residual tower in one LDS-resident MFMA kernel (csrc/yy_tower.hip, yy_tower12.hip).
+    """Stem + residual tower in one LDS-resident MFMA kernel (csrc/yy_tower.hip, yy_towerq.hip).
     planes f32 [G,5,R,R] (R = 8 or 12) -> bf16 activations as a channels-last tensor [G,128,R,R]."""
     G, _, R, Cc = planes.shape
     _need(planes, torch.float32, (G, 5, R, Cc), "planes")

@@ -238,7 +238,7 @@ class BatchedEvaluator:
         self.mode = mode
         self.device = next(net.parameters()).device
         self.fused = bool(fused_epilogue) and mode == "bf16"
-        # the LDS-resident MFMA tower kernels (csrc/yy_tower.hip 8x8, yy_tower12.hip 12x12, yy_tower6.hip 6x6) cover the stem + residual
+        # the LDS-resident MFMA tower kernels (csrc/yy_tower.hip 8x8, yy_towerq.hip 6x6 / 12x12 / small 8x8 batches) cover the stem + residual
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
                       and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
