@@ -232,6 +232,48 @@ def test_engine_full_games_properties(pkg, use_graph, row_tiers):
     eng.close()
 
 
+@pytest.mark.parametrize("shape,G,games,sims,semantics", [((6, 6), 64, 80, 40, "copied"), ((8, 8), 96, 96, 32, "copied"),
+                                                         ((5, 7), 40, 40, 24, "aliased")],
+                         ids=["6x6_copied_refill", "8x8_copied_packed_tail", "5x7_aliased"])
+def test_engine_every_policy_equals_oracle_search(pkg, shape, G, games, sims, semantics):
+    """End-to-end parity of the BATCHED lockstep engine (hipGraph replay, slot refill, packed tail): with the exact hash
+    evaluator and no root noise, EVERY recorded pi of every game must be the oracle's search result from that recorded state
+    for the side that then moved (tolerance 0 after the float32 cast the engine applies when it stores pi)."""
+    import torch
+    from hash_eval import hash_eval_torch
+    R, C = shape
+    game = pkg.YinYangGame(R, C)
+    ev = lambda planes: hash_eval_torch(planes, 10, 11)
+    eng = pkg.SelfPlayEngine(game, ev, num_simulations=sims, concurrent_games=G, seed=21, dirichlet_epsilon=0.0,
+                             board_semantics=semantics, row_tiers=(8, 16, 32, 64))
+    ex = eng.run(games)
+    assert eng.games_finished == games
+    st, pi, gid, ply = (ex[k].cpu().numpy() for k in ("states", "policies", "game_id", "ply"))
+    checked = 0
+    for g in np.unique(gid):
+        sel = np.flatnonzero(gid == g)
+        sel = sel[np.argsort(ply[sel])]
+        for a, b in zip(sel[:-1], sel[1:]):
+            d = (st[b].astype(np.int32) - st[a].astype(np.int32)).reshape(-1)
+            cells = np.flatnonzero(d)
+            if semantics == "aliased" or len(cells) != 1:
+                continue       # aliased: the recorded state is already mutated by its own search (Q2); checked below instead
+            mover = int(d[cells[0]])
+            r = O.search_hash(st[a], mover, sims, 1, 10, 11, noise=None, eps=0.0)
+            assert np.array_equal(r.pi.astype(np.float32), pi[a]), (int(g), int(ply[a]))
+            checked += 1
+    if semantics == "copied":
+        assert checked > games * 5
+    else:
+        # literal aliased semantics: every game starts from the empty board as black; its first recorded pi must be the
+        # oracle's aliased search from the empty board, and the oracle's mutated final board is where play continues from
+        r = O.search_hash(np.zeros((R, C), np.int8), 1, sims, 0, 10, 11, noise=None, eps=0.0)
+        for g in np.unique(gid):
+            first = np.flatnonzero((gid == g) & (ply == 0))
+            assert len(first) == 1 and np.array_equal(r.pi.astype(np.float32), pi[first[0]])
+    eng.close()
+
+
 def test_engine_graph_equals_eager(pkg):
     """hipGraph replay of the simulation loop gives the same visit counts as eager launches."""
     import torch
