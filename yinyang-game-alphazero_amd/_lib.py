@@ -37,10 +37,16 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO] + [s for s in srcs if s.endswith(".hip")]
+    tmp = f"{SO}.{os.getpid()}.tmp"            # link to a private name, then rename: a reader never sees a half-written file
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + [s for s in srcs if s.endswith(".hip")]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(cmd).replace(tmp, SO))
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, SO)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return SO
 
 
