@@ -118,3 +118,46 @@ def test_trainer_ddp_gloo_world2(tmp_path):
     import re
     losses = re.findall(r"ok (\[[^\]]*\])", r.stdout)
     assert len(losses) == 2 and losses[0] == losses[1], r.stdout[-500:]      # same global loss on both ranks
+
+
+def test_reference_format_writer_round_trip(tmp_path):
+    """save_examples_reference_format: the pickle stream must name the reference's class by its module path (so the
+    reference rebuilds ITS OWN board objects) and nothing of this package; a stand-in module with that path is enough to load
+    the file the way the reference does (training_pipeline.py:67-73) and to call get_board() on every element; the plain
+    keys stay readable without unpickling."""
+    import pickletools
+    import sys
+    import types
+    import zipfile
+    from yinyang_game_alphazero_amd.training import load_examples, save_examples_reference_format
+    rng = np.random.default_rng(0)
+    states = rng.integers(-1, 2, size=(7, 6, 6)).astype(np.int8)
+    pol = rng.dirichlet(np.ones(36), size=7)
+    val = rng.choice([-1.0, 1.0, 1e-4], size=7)
+    path = save_examples_reference_format(str(tmp_path / "self_play_data_1.npz"), states, pol, val)
+    assert "src.yin_yang.yin_yang_logic" not in sys.modules                   # the shim module is gone again
+    raw = zipfile.ZipFile(path).read("boards.npy")
+    names = {arg for op, arg, _ in pickletools.genops(raw[raw.index(b"\x80"):]) if op.name in ("GLOBAL", "STACK_GLOBAL", "SHORT_BINUNICODE", "BINUNICODE")}
+    assert "src.yin_yang.yin_yang_logic" in names and "YinYangLogic" in names
+    assert not any("yinyang_game_alphazero_amd" in str(n) or "yinyang-game" in str(n) for n in names)
+    ex = load_examples(path)                                                  # this package: plain keys, allow_pickle=False
+    assert np.array_equal(ex["states"].numpy(), states) and np.allclose(ex["policies"].numpy(), pol.astype(np.float32))
+
+    class YinYangLogic:                                                        # what the reference's module provides
+        def get_board(self):
+            return self.board.copy()
+
+    for n in ("src", "src.yin_yang", "src.yin_yang.yin_yang_logic"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["src.yin_yang.yin_yang_logic"].YinYangLogic = YinYangLogic
+    try:
+        data = np.load(path, allow_pickle=True)                               # OUR OWN file, written two lines above
+        boards, policies, values = data["boards"], data["policies"], data["values"]
+        examples = [(boards[i], policies[i], values[i]) for i in range(len(boards))]
+    finally:
+        for n in ("src", "src.yin_yang", "src.yin_yang.yin_yang_logic"):
+            del sys.modules[n]
+    assert len(examples) == 7 and all(isinstance(b, YinYangLogic) for b, _, _ in examples)
+    for i, (b, p, v) in enumerate(examples):
+        assert np.array_equal(b.get_board(), states[i]) and (b.n, b.m) == (6, 6) and b.board.dtype == np.int8
+        assert np.array_equal(p, pol[i]) and v == val[i]

@@ -43,6 +43,8 @@ def parse_args(argv=None):
     p.add_argument("--nn", choices=["bf16", "fp32", "fp32t", "bf16x3"], default="bf16",
                    help="evaluator: bf16 tower (default), fp32 module, exact-f32 tower, split-bf16 tower (f32-grade accuracy)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--reference-format", action="store_true",
+                   help="self-play: also store the reference's pickled board objects so its own training pipeline reads the file")
     p.add_argument("--arena-games", type=int, default=40)
     p.add_argument("--channels", type=int, default=128)
     p.add_argument("--blocks", type=int, default=10)
@@ -89,7 +91,8 @@ def main(argv=None):
                                        num_workers=args.workers, num_simulations=args.simulations,
                                        concurrent_games=args.concurrent_games, board_semantics=args.board_semantics,
                                        reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed,
-                                       num_channels=args.channels, num_res_blocks=args.blocks)
+                                       num_channels=args.channels, num_res_blocks=args.blocks,
+                                       reference_format=args.reference_format)
     if rank == 0:
         st = pkg.generate_self_play_data.last_stats
         st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])

@@ -480,10 +480,11 @@ class SelfPlayManager:
 
 
 def generate_self_play_data(game, model_path, output_dir, num_games=100, num_workers=1, num_simulations=800,
-                            **engine_kwargs):
+                            reference_format=False, **engine_kwargs):
     """self_play.py:337-387: same arguments and the same file name pattern.  The .npz holds plain
     tensors (`states` int8 [N,R,C], `policies` float64 [N,A], `values` float64 [N]; `boards` is an
-    alias of `states`) instead of pickled board objects."""
+    alias of `states`) instead of pickled board objects; `reference_format=True` writes the reference's pickled-object
+    layout as well (training.save_examples_reference_format) so that the reference's training pipeline can read the file."""
     os.makedirs(output_dir, exist_ok=True)
     games_per_worker = max(1, num_games // num_workers)               # :355 (remainder dropped)
     manager = SelfPlayManager(game, model_path, num_workers=num_workers, games_per_worker=games_per_worker,
@@ -492,7 +493,12 @@ def generate_self_play_data(game, model_path, output_dir, num_games=100, num_wor
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}.npz")
-    if rank == 0:
+    if rank == 0 and reference_format:
+        # `boards` = pickled board objects of the reference's own class, readable by ITS TrainingDataQueue.push_file
+        from .training import save_examples_reference_format
+        save_examples_reference_format(filename, ex["states"].cpu().numpy(), ex["policies"].cpu().numpy(),
+                                       ex["values"].cpu().numpy())
+    elif rank == 0:
         states = ex["states"].cpu().numpy()
         np.savez(filename, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
                  values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),

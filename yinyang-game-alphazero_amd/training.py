@@ -48,6 +48,47 @@ def augment_batch(planes, policies):
     return torch.cat([o[0] for o in outs]).contiguous(), torch.cat([o[1] for o in outs]).contiguous()
 
 
+def save_examples_reference_format(path, states, policies, values):
+    """Write a self_play_data_*.npz the REFERENCE's own loader reads (training_pipeline.py:56-77: `np.load(allow_pickle=True)`,
+    then `boards[i].get_board()` via neural_network.py:178): `boards` is an object array whose elements unpickle, inside the
+    reference's process, as instances of ITS class `src.yin_yang.yin_yang_logic.YinYangLogic` (attributes n, m, board --
+    yin_yang_logic.py:14-18).  Nothing of the reference is imported to write it: a stand-in class carrying the reference's
+    module path and name is registered under that module name only while the file is pickled, so the stream holds the
+    global reference `src.yin_yang.yin_yang_logic YinYangLogic` plus plain state.  `states`, `policies`, `values` are
+    stored beside it as plain arrays, so this package's loader (allow_pickle=False on those keys) reads the same file."""
+    import sys
+    import types
+    states = np.ascontiguousarray(states, dtype=np.int8)
+    mod_name = "src.yin_yang.yin_yang_logic"
+
+    class YinYangLogic:                  # state only; methods come from the reference's class when IT unpickles
+        pass
+
+    YinYangLogic.__module__, YinYangLogic.__qualname__ = mod_name, "YinYangLogic"
+    boards = np.empty(states.shape[0], dtype=object)
+    for i in range(states.shape[0]):
+        b = YinYangLogic()
+        b.n, b.m, b.board = int(states.shape[1]), int(states.shape[2]), states[i].copy()
+        boards[i] = b
+    # pickle resolves a class by importing its module path, parents included: stand-ins for all three names, only for
+    # the duration of the write (whatever was registered under those names before is put back)
+    names = ["src", "src.yin_yang", mod_name]
+    saved = {n: sys.modules.get(n) for n in names}
+    for n in names:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules[mod_name].YinYangLogic = YinYangLogic
+    try:
+        np.savez(path, boards=boards, states=states, policies=np.asarray(policies, dtype=np.float64),
+                 values=np.asarray(values, dtype=np.float64))
+    finally:
+        for n in names:
+            if saved[n] is None:
+                del sys.modules[n]
+            else:
+                sys.modules[n] = saved[n]
+    return path
+
+
 def load_examples(path):
     """Read a self_play_data_*.npz written by generate_self_play_data (plain arrays, no pickles)."""
     z = np.load(path, allow_pickle=False)
