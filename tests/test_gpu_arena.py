@@ -20,6 +20,9 @@ def test_arena_accounting_and_symmetry():
     # against the uniformly random player
     res2 = pkg.Arena(game, ev, "random", num_simulations=12, seed=2).play(16)
     assert res2["a_wins"] + res2["b_wins"] + res2["draws"] == 16
+    # the reference's literal attribution is available as a switch; totals still add up
+    res4 = pkg.Arena(game, ev, "random", num_simulations=12, seed=2, reference_scoring=True).play(16)
+    assert res4["a_wins"] + res4["b_wins"] + res4["draws"] == 16
     # random vs random needs no search at all
     res3 = pkg.Arena(game, "random", "random", num_simulations=1, seed=3).play(32)
     assert res3["a_wins"] + res3["b_wins"] + res3["draws"] == 32 and res3["a_wins"] > 0 and res3["b_wins"] > 0

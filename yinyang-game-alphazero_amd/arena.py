@@ -82,8 +82,12 @@ class Arena:
     (planes -> policy, value) searched with `num_simulations`, or the string "random" (uniformly random
     legal moves, RandomPlayer)."""
 
-    def __init__(self, game, player_a, player_b, num_simulations=800, cpuct=1.0, device=None, seed=0):
+    def __init__(self, game, player_a, player_b, num_simulations=800, cpuct=1.0, device=None, seed=0,
+                 reference_scoring=False):
+        """reference_scoring=True reproduces the reference's attribution literally (alphazero.py:206-218): the value of
+        getGameEnded for the player who would move NEXT is read as "+1 = black won, -1 = white won"."""
         self.game = game
+        self.reference_scoring = bool(reference_scoring)
         self.R, self.C = game.getBoardSize()
         self.A = self.R * self.C
         self.pa, self.pb, self.sims, self.cpuct = player_a, player_b, num_simulations, cpuct
@@ -143,6 +147,8 @@ class Arena:
             over = alive & (ended != 0)
             diff = (counts[:, 0] - counts[:, 1])
             res = torch.where(diff > 0, 1, torch.where(diff < 0, -1, 2)).to(torch.int8)
+            if self.reference_scoring:
+                res = torch.where(ended == 1, 1, torch.where(ended == -1, -1, 2)).to(torch.int8)
             result = torch.where(over, res, result)
             alive &= ~over
         ctx.status()
