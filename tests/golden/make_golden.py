@@ -15,6 +15,7 @@ Fixture families:
      search_net_8x8.npz    MCTS.search with the real seeded 128x10 net, evaluator outputs recorded
   G4 episodes.npz          SelfPlayWorker.play_game transcripts (literal and copied adapter)
   G6 augment.npz           DataProcessor.augment_sample: the 8 symmetric (planes, policy) variants
+  G8 symmetries.npz        YinYangGame.getSymmetries: the 8 (board, pi) forms in the reference's order
   G7 ucb.npz               Node.select_child on random child statistics (ties, unvisited children, f32 / python-float sums)
 
 The reference imports create mcts.log / neural_network.log / training.log in the
@@ -512,6 +513,32 @@ def gen_g6():
     print("wrote", path, flush=True)
 
 
+def gen_sym():
+    """G8 symmetries.npz: YinYangGame.getSymmetries (yin_yang_game.py:127-166) on random square boards: the 8 (board, pi) forms
+    in the reference's order."""
+    YinYangGame, YinYangLogic, _ = _import_ref()
+    rng = np.random.default_rng(88)
+    out = {}
+    for (R, C) in ((4, 4), (6, 6), (8, 8)):
+        game = YinYangGame(R, C)
+        n = 6
+        boards = rng.integers(-1, 2, size=(n, R, C)).astype(np.int8)
+        pis = rng.dirichlet(np.ones(R * C), size=n)
+        sb = np.zeros((n, 8, R, C), np.int8)
+        sp = np.zeros((n, 8, R * C), np.float64)
+        for i in range(n):
+            lb = YinYangLogic(R, C)
+            lb.board = boards[i].copy()
+            syms = game.getSymmetries(lb, pis[i])
+            assert len(syms) == 8
+            for k, (b, p) in enumerate(syms):
+                sb[i, k], sp[i, k] = b.get_board(), p
+        out[f"boards_{R}"], out[f"pis_{R}"], out[f"sym_boards_{R}"], out[f"sym_pis_{R}"] = boards, pis, sb, sp
+    path = os.path.join(OUT, "symmetries.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, flush=True)
+
+
 def gen_ucb():
     """G7 ucb.npz: Node.select_child (mcts.py:97-145) on random child statistics, with ties, unvisited children, python-float
     and float32 value sums."""
@@ -570,6 +597,8 @@ def main():
         gen_g6()
     if "ucb" in only:
         gen_ucb()
+    if "sym" in only:
+        gen_sym()
     if "edge" in only:      # degenerate and maximum geometries (1 x N, N x 1, 2 x 2, the 192-cell / 16-wide limits)
         gen_g1([(1, 1), (1, 6), (7, 1), (2, 2), (2, 9), (13, 14), (16, 12), (12, 16)], 256, pool)
         gen_g2([(1, 6), (7, 1), (16, 12)], 64)

@@ -221,3 +221,24 @@ def test_node_view_select_child_matches_reference_golden():
             node.children[a] = ch
         bad += int(node.select_child(float(z["cpuct"][i]))[0] != int(z["chosen"][i]))
     assert bad == 0
+
+
+def test_game_helpers_match_reference_golden():
+    """symmetries.npz (G8): YinYangGame.getSymmetries against the reference's 8 (board, pi) forms, same order; plus the other
+    host-only helpers (canonical form = identity, action <-> coords, stringRepresentation = the board bytes)."""
+    import yinyang_game_alphazero_amd as pkg
+    with np.load(os.path.join(ROOT, "tests", "golden", "symmetries.npz")) as f:
+        z = {k: f[k] for k in f.files}
+    for R in (4, 6, 8):
+        game = pkg.YinYangGame(R, R)
+        for i in range(z[f"boards_{R}"].shape[0]):
+            lb = pkg.YinYangLogic(R, R)
+            lb.board = z[f"boards_{R}"][i].copy()
+            syms = game.getSymmetries(lb, z[f"pis_{R}"][i])
+            assert len(syms) == 8
+            for k, (b, p) in enumerate(syms):
+                assert np.array_equal(b.get_board(), z[f"sym_boards_{R}"][i, k]) and np.array_equal(p, z[f"sym_pis_{R}"][i, k])
+            assert game.getCanonicalForm(lb, -1) is lb
+            assert game.stringRepresentation(lb) == z[f"boards_{R}"][i].tobytes()
+        assert game._action_to_coords(R + 1) == (1, 1) and game._coords_to_action(2, 3) == 2 * R + 3
+        assert game.getBoardSize() == (R, R) and game.getActionSize() == R * R
