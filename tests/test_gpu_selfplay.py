@@ -131,6 +131,38 @@ def test_search_invariants_like_reference_tests(pkg, semantics):
     m.close()
 
 
+def test_node_built_by_hand_like_reference_tests(pkg):
+    """mcts_tests.py:84-157 (TestNode: init, expand, expand_terminal, select_child, update, get_value) restated with the
+    reference's constructor `Node(game)` on the real 3x3 game (rules from the HIP kernels through the game shim)."""
+    game = pkg.YinYangGame(3, 3)
+    node = pkg.Node(game)
+    assert node.game is game and node.parent is None and node.action is None and node.children == {}
+    assert node.visits == 0 and node.value_sum == 0.0 and node.prior == 0.0 and not node.is_expanded()
+    board = game.getInitBoard()
+    policy = np.ones(9, np.float32) / 9
+    node.expand(board, 1, policy)
+    assert node.board is board and node.player == 1 and not node.is_terminal and node.is_expanded()
+    assert sorted(node.children) == list(range(9)) and all(ch.prior == policy[a] and ch.parent is node and ch.action == a
+                                                           for a, ch in node.children.items())
+    assert np.array_equal(node.valid_moves, np.ones(9))
+    other = pkg.Node(game)
+    other.expand(board, 1, None)                                   # no policy: uniform over the legal moves (:81)
+    assert all(abs(ch.prior - 1.0 / 9) < 1e-15 for ch in other.children.values())
+    # terminal expansion (:63-71): a full board without legal moves for either colour
+    full = pkg.YinYangLogic(3, 3)
+    full.board = np.array([[1, -1, 1], [-1, 1, -1], [1, -1, -1]], np.int8)
+    term = pkg.Node(game)
+    term.expand(full, 1, policy)
+    assert term.is_terminal and term.is_expanded() and term.children == {} and term.terminal_value == game.getGameEnded(full, 1) != 0
+    # select_child / update / get_value on the expanded node (:117-157)
+    node.children[4].visits, node.children[4].value_sum = 3, np.float32(2.4)
+    a, ch = node.select_child(c_puct=1.0)
+    assert a == 4 and ch is node.children[4]                       # q = 0.8 dominates the equal priors
+    ch.update(0.5)
+    assert ch.visits == 4 and abs(float(ch.value_sum) - 2.9) < 1e-6 and abs(float(ch.get_value()) - 0.725) < 1e-6
+    assert pkg.Node(game).get_value() == 0.0
+
+
 def test_terminal_root_and_only_move(pkg):
     game = pkg.YinYangGame(3, 3)
     # full board: terminal root, value from the root player's view, no children, uniform pi (:252-269, mcts.py:209-213)

@@ -22,14 +22,32 @@ from .game import YinYangLogic
 
 
 class Node:
-    """Read-only view with the reference's field names (mcts.py:32-48)."""
+    """Host view of a tree node with the reference's constructor, fields and methods (mcts.py:28-215).  The searched tree
+    itself lives in HBM; `MCTS.search` returns a view of the root and its children.  A Node built by hand (as the
+    reference's tests do) works on the host: `expand` asks the game for the legal moves / outcome, `select_child`,
+    `update` and the distribution helpers follow the reference's arithmetic."""
 
-    def __init__(self, action=None, prior=0.0, visits=0, value_sum=0.0, parent=None):
+    def __init__(self, game=None, parent=None, action=None, prior=0.0, visits=0, value_sum=0.0):
+        self.game = game
         self.parent, self.action = parent, action
         self.children = {}
         self.visits, self.value_sum, self.prior = visits, value_sum, prior
         self.board = self.player = self.valid_moves = None
         self.is_terminal, self.terminal_value = False, None
+
+    def expand(self, board, player, policy_probs):
+        """mcts.py:50-91: terminal -> store the value, no children; else one child per legal move, ascending action, with
+        the RAW policy entry as prior (uniform over the legal moves when no policy is given)."""
+        self.board, self.player = board, player
+        result = self.game.getGameEnded(board, player)
+        if result != 0:
+            self.is_terminal, self.terminal_value = True, result
+            return
+        self.valid_moves = self.game.getValidMoves(board, player)
+        legal = np.where(self.valid_moves == 1)[0]
+        for a in legal:
+            prior = policy_probs[a] if policy_probs is not None else 1.0 / len(legal)
+            self.children[a] = Node(game=self.game, parent=self, action=a, prior=prior)
 
     def is_expanded(self):
         return len(self.children) > 0 or self.is_terminal
@@ -204,12 +222,12 @@ class MCTS:
             board.board[...] = ctx.boards()[0].cpu().numpy()     # the reference mutates the caller's board
         ctx.status()
         counts, cw, cp = counts[0].cpu().numpy(), cw[0].cpu().numpy(), cp[0].cpu().numpy()
-        root = Node(visits=int(visits[0]), value_sum=float(wsum[0]))
+        root = Node(game=self.game, visits=int(visits[0]), value_sum=float(wsum[0]))
         root.board, root.player = board, player
         root.is_terminal, root.terminal_value = (terminal != 0), (terminal if terminal != 0 else None)
         root.valid_moves = valid.astype(np.float64)
         for a in (np.flatnonzero(valid) if terminal == 0 else []):
-            root.children[int(a)] = Node(action=int(a), prior=np.float32(cp[a]), visits=int(counts[a]),
+            root.children[int(a)] = Node(game=self.game, action=int(a), prior=np.float32(cp[a]), visits=int(counts[a]),
                                          value_sum=np.float32(cw[a]), parent=root)
         return pi[0].cpu().numpy(), root
 
