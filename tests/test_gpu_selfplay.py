@@ -211,6 +211,27 @@ def test_game_api_matches_oracle(pkg):
     assert game.getBoardSize() == (5, 7) and game.getActionSize() == 35 and game._action_to_coords(17) == (2, 3)
 
 
+def test_logic_predicates_compose_to_the_legal_mask(pkg):
+    """yin_yang_logic.py:31-56: is_valid_move == in-bounds, empty, and with the stone placed: _check_connectivity(piece) and
+    _check_2x2_constraint().  The two host predicates of the shim must compose to exactly the device kernel's mask (which the
+    goldens pin to the reference) on random boards, both colours."""
+    rng = np.random.default_rng(9)
+    for (R, C) in ((5, 5), (4, 7), (8, 8)):
+        lb = pkg.YinYangLogic(R, C)
+        for _ in range(12):
+            lb.board = (rng.integers(-1, 2, size=(R, C)) * (rng.random((R, C)) < rng.uniform(0.2, 0.9))).astype(np.int8)
+            for piece in (1, -1):
+                mask = lb._mask(piece).reshape(R, C)
+                for x in range(R):
+                    for y in range(C):
+                        ok = False
+                        if lb.board[x, y] == 0:
+                            lb.board[x, y] = piece
+                            ok = lb._check_connectivity(piece) and lb._check_2x2_constraint()
+                            lb.board[x, y] = 0
+                        assert ok == bool(mask[x, y]), (R, C, x, y, piece)
+
+
 @pytest.mark.parametrize("use_graph,row_tiers", [(False, ()), (False, (8, 16, 32, 64)), (True, (8, 16, 32, 64))],
                          ids=["full_rows", "packed_tail", "packed_tail_graph"])
 def test_engine_full_games_properties(pkg, use_graph, row_tiers):

@@ -161,3 +161,22 @@ def test_reference_format_writer_round_trip(tmp_path):
     for i, (b, p, v) in enumerate(examples):
         assert np.array_equal(b.get_board(), states[i]) and (b.n, b.m) == (6, 6) and b.board.dtype == np.int8
         assert np.array_equal(p, pol[i]) and v == val[i]
+
+
+def test_pipeline_model_performance(tmp_path):
+    """TrainingPipeline.get_model_performance (a None-returning stub in the reference): losses on a queue sample, CPU."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(4, 4)
+    pipe = pkg.TrainingPipeline(game, model_dir=str(tmp_path / "m"), data_dir=str(tmp_path / "d"), device="cpu",
+                                num_channels=8, num_res_blocks=1, sample_size=16)
+    assert pipe.get_model_performance() is None                         # empty queue
+    rng = np.random.default_rng(0)
+    ex = [(rng.integers(-1, 2, size=(4, 4)).astype(np.int8), rng.dirichlet(np.ones(16)), float(rng.choice([-1, 1]))) for _ in range(20)]
+    pipe.data_queue.push_examples(ex)
+    m = pipe.get_model_performance()
+    assert set(m) == {"policy_loss", "value_loss", "total_loss", "examples"} and m["examples"] == 16
+    assert abs(m["total_loss"] - m["policy_loss"] - m["value_loss"]) < 1e-5 and m["policy_loss"] > 0
+    pipe.trainer.save_checkpoint("probe.pth.tar")
+    m2 = pipe.get_model_performance(str(tmp_path / "m" / "probe.pth.tar"))
+    assert m2["examples"] == 16 and m2["total_loss"] > 0

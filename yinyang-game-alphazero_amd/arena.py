@@ -193,6 +193,11 @@ class AlphaZeroPlayer:
             return -1
         return int(self.mcts.select_action(board, player, temperature=0, valid_moves=valid))
 
+    def notify(self, board, action):
+        """alphazero.py:354-364: keep the subtree under the opponent's move (the reference never searches from it either)."""
+        if self.root is not None:
+            self.root = self.mcts.reuse_tree(self.root, board, -1, action)
+
 
 def _load_evaluator(game, path, device, nn_mode, num_channels, num_res_blocks):
     net = YinYangNeuralNetwork(game, num_channels, num_res_blocks)

@@ -62,6 +62,30 @@ class YinYangLogic:
     def count_pieces(self):
         return int(np.sum(self.board == 1)), int(np.sum(self.board == -1))
 
+    # the two predicates is_valid_move is made of in the reference (yin_yang_logic.py:58-109); host numpy on the current
+    # board, kept for callers that probe them directly -- the kernels evaluate the fused form
+    def _check_connectivity(self, piece):
+        """True when colour `piece` is absent or forms one 4-connected group."""
+        cells = np.argwhere(self.board == piece)
+        if len(cells) == 0:
+            return True
+        todo, seen = [tuple(cells[0])], {tuple(cells[0])}
+        while todo:
+            x, y = todo.pop()
+            for nx, ny in ((x + 1, y), (x - 1, y), (x, y + 1), (x, y - 1)):
+                if 0 <= nx < self.n and 0 <= ny < self.m and self.board[nx, ny] == piece and (nx, ny) not in seen:
+                    seen.add((nx, ny))
+                    todo.append((nx, ny))
+        return len(seen) == len(cells)
+
+    def _check_2x2_constraint(self):
+        """True when no 2x2 window holds four equal stones (either colour)."""
+        b = self.board
+        if self.n < 2 or self.m < 2:
+            return True
+        same = (b[:-1, :-1] == b[1:, :-1]) & (b[:-1, :-1] == b[:-1, 1:]) & (b[:-1, :-1] == b[1:, 1:]) & (b[:-1, :-1] != 0)
+        return not bool(same.any())
+
 
 class YinYangGame:
     """AlphaZero Game interface (yin_yang_game.py:4-206)."""

@@ -354,6 +354,28 @@ class TrainingPipeline:
                 allm[k].extend(m.get(k, []))
         return allm
 
+    def get_model_performance(self, model_path=None):
+        """training_pipeline.py:280-291 is a stub that returns None; here: policy / value / total loss of the model (the
+        trainer's current weights, or the checkpoint at `model_path`) on a sample of the queue, no gradient.  None when the
+        queue is empty."""
+        ex = self.data_queue.sample()
+        if not ex or len(ex["values"]) == 0:
+            return None
+        net = self.trainer.nnet
+        if model_path is not None:
+            net = YinYangNeuralNetwork(self.game, net.conv1.out_channels, len(net.res_blocks))
+            net.load_model(model_path)
+            net = net.to(self.trainer.device)
+        was_training = net.training
+        net.eval()
+        with torch.no_grad():
+            planes = self.trainer._encode(ex["states"])
+            logits, v = net(planes)
+            pl = F.cross_entropy(logits, ex["policies"].to(self.trainer.device).float())
+            vl = F.mse_loss(v.reshape(-1), ex["values"].to(self.trainer.device).float())
+        net.train(was_training)
+        return {"policy_loss": float(pl), "value_loss": float(vl), "total_loss": float(pl + vl), "examples": int(len(ex["values"]))}
+
     def get_latest_model_path(self):
         name = f"checkpoint_{self.iteration}.pth.tar" if self.iteration > 0 else "checkpoint.pth.tar"
         return os.path.join(self.model_dir, name)
