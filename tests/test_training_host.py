@@ -180,3 +180,31 @@ def test_pipeline_model_performance(tmp_path):
     pipe.trainer.save_checkpoint("probe.pth.tar")
     m2 = pipe.get_model_performance(str(tmp_path / "m" / "probe.pth.tar"))
     assert m2["examples"] == 16 and m2["total_loss"] > 0
+
+
+def test_data_processor_api_matches_reference_golden():
+    """data_utils.DataProcessor / create_dataset_from_games with the reference's signatures, against the G6 fixture (the
+    reference's augment_sample outputs, exact) and the oracle's plane encoding."""
+    import yinyang_game_alphazero_amd as pkg
+    z = np.load(os.path.join(GOLDEN, "augment.npz"))
+    game = pkg.YinYangGame(6, 6)
+    proc = pkg.DataProcessor(game)
+    assert proc.board_size == (6, 6)
+    boards, pi = z["boards_6"], z["pi_6"]
+    want_p, want_pi = z["aug_planes_6"], z["aug_pi_6"]
+    for n in range(3):
+        lb = pkg.YinYangLogic(6, 6)
+        lb.board = boards[n].copy()
+        bt, pt = proc.preprocess_sample(lb, pi[n], 1)
+        assert np.array_equal(bt.numpy(), O.encode_planes(boards[n:n + 1])[0]) and pt.dtype == torch.float32
+        aug = proc.augment_sample(bt, pt)
+        assert len(aug) == 8
+        for v, (ab, ap) in enumerate(aug):
+            assert np.array_equal(ab.numpy(), want_p[n, v]) and np.array_equal(ap.numpy(), want_pi[n, v].astype(np.float32))
+    g = proc._policy_to_grid(pi[0])
+    assert g.shape == (6, 6) and np.array_equal(proc._grid_to_policy(g).numpy(), pi[0].astype(np.float32))
+    data = [(boards[n], pi[n], float(n % 2 * 2 - 1)) for n in range(4)]
+    b, p, v = pkg.create_dataset_from_games(data, game, augment=True)
+    assert len(b) == len(p) == len(v) == 32 and np.array_equal(b[8 + 3].numpy(), want_p[1, 3]) and float(v[8 + 3]) == 1.0
+    b, p, v = pkg.create_dataset_from_games(data, game, augment=False)
+    assert len(b) == 4 and np.array_equal(p[2].numpy(), pi[2].astype(np.float32))

@@ -22,6 +22,7 @@ def __getattr__(name):
         "generate_self_play_data": ".self_play", "SelfPlayEngine": ".self_play",
         "training": ".training", "AlphaZeroTrainer": ".training", "TrainingDataQueue": ".training",
         "TrainingPipeline": ".training", "run_training_pipeline": ".training", "augment_batch": ".training",
+        "DataProcessor": ".training", "create_dataset_from_games": ".training",
         "arena": ".arena", "Arena": ".arena", "AlphaZero": ".arena", "AlphaZeroPlayer": ".arena",
         "RandomPlayer": ".arena", "evaluate_vs_random": ".arena",
     }

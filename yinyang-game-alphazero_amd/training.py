@@ -48,6 +48,62 @@ def augment_batch(planes, policies):
     return torch.cat([o[0] for o in outs]).contiguous(), torch.cat([o[1] for o in outs]).contiguous()
 
 
+def encode_planes_host(states):
+    """int8 [N,R,C] -> planes f32 [N,5,R,C] with torch ops on the tensor's own device (neural_network.py:156-196: fractions
+    formed in float64, stored as float32).  The trainer uses the HIP encode kernel on a ROCm device and this elsewhere."""
+    b = states.to(torch.int8)
+    occ = (b != 0)
+    n, m = b.shape[1:]
+    rows = (occ.sum(2).double() / m).float()[:, :, None].expand(-1, n, m)
+    cols = (occ.sum(1).double() / n).float()[:, None, :].expand(-1, n, m)
+    return torch.stack([(b == 0).float(), (b == 1).float(), (b == -1).float(), rows, cols], dim=1)
+
+
+class DataProcessor:
+    """data_utils.py:7-180 with the same methods, on top of the batched routines of this module (one sample = a batch of
+    one).  `augment_sample` returns the reference's 8 variants in its order (pinned by the G6 fixture)."""
+
+    def __init__(self, game):
+        self.game = game
+        self.board_size = game.getBoardSize()
+
+    def preprocess_sample(self, board, policy, player):
+        """board object (get_board()) or int8 array -> (planes f32 [5,R,C], policy FloatTensor [A]); `player` is unused,
+        as in the reference (:16-37)."""
+        arr = board.get_board() if hasattr(board, "get_board") else np.asarray(board)
+        planes = encode_planes_host(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int8))[None])[0]
+        return planes, torch.as_tensor(np.asarray(policy), dtype=torch.float32)
+
+    def augment_sample(self, board, policy):
+        """(planes [5,R,R], policy [A]) -> list of 8 (planes, policy) pairs (:39-134)."""
+        ap, api = augment_batch(board[None], torch.as_tensor(policy, dtype=torch.float32)[None])
+        return [(ap[v], api[v]) for v in range(8)]
+
+    def _policy_to_grid(self, policy):
+        n, m = self.board_size
+        if isinstance(policy, torch.Tensor):
+            policy = policy.detach().cpu().numpy()
+        return np.where(np.asarray(policy) > 0, policy, 0.0).reshape(n, m).astype(np.float64)
+
+    def _grid_to_policy(self, policy_grid):
+        g = np.asarray(policy_grid, dtype=np.float64)
+        return torch.FloatTensor(np.where(g > 0, g, 0.0).reshape(-1))
+
+
+def create_dataset_from_games(game_data, game, augment=True):
+    """data_utils.py:182-220: list of (board, policy, value) -> three lists of tensors (8 entries per sample when
+    augmenting, sample-major like the reference's loop)."""
+    proc = DataProcessor(game)
+    boards, policies, values = [], [], []
+    for board, policy, value in game_data:
+        bt, pt = proc.preprocess_sample(board, policy, 1)
+        for ab, ap in (proc.augment_sample(bt, pt) if augment else [(bt, pt)]):
+            boards.append(ab)
+            policies.append(ap)
+            values.append(torch.FloatTensor([value]))
+    return boards, policies, values
+
+
 def save_examples_reference_format(path, states, policies, values):
     """Write a self_play_data_*.npz the REFERENCE's own loader reads (training_pipeline.py:56-77: `np.load(allow_pickle=True)`,
     then `boards[i].get_board()` via neural_network.py:178): `boards` is an object array whose elements unpickle, inside the
@@ -179,12 +235,7 @@ class AlphaZeroTrainer:
         if self.device.type == "cuda":
             from . import engine
             return engine.encode_planes(states.to(self.device).contiguous())
-        b = states.to(torch.int8)
-        occ = (b != 0)
-        n, m = b.shape[1:]
-        rows = (occ.sum(2).double() / m).float()[:, :, None].expand(-1, n, m)
-        cols = (occ.sum(1).double() / n).float()[:, None, :].expand(-1, n, m)
-        return torch.stack([(b == 0).float(), (b == 1).float(), (b == -1).float(), rows, cols], dim=1)
+        return encode_planes_host(states)
 
     def train(self, examples, epochs=10, augment=True):
         """trainer.py:67-161.  examples: dict of tensors (or the reference's list of tuples)."""
