@@ -208,3 +208,48 @@ def test_data_processor_api_matches_reference_golden():
     assert len(b) == len(p) == len(v) == 32 and np.array_equal(b[8 + 3].numpy(), want_p[1, 3]) and float(v[8 + 3]) == 1.0
     b, p, v = pkg.create_dataset_from_games(data, game, augment=False)
     assert len(b) == 4 and np.array_equal(p[2].numpy(), pi[2].astype(np.float32))
+
+
+def test_reference_format_reader_is_restricted(tmp_path):
+    """Reading direction: a file in the reference's pickled-board layout (written here by our own compat writer, WITHOUT the
+    plain `states` key) is refused by default, read through the restricted unpickler on request, and a stream naming any
+    other global is rejected before anything runs."""
+    import io
+    import pickle
+    import zipfile
+    from yinyang_game_alphazero_amd.training import TrainingDataQueue, load_examples, save_examples_reference_format
+    rng = np.random.default_rng(3)
+    states = rng.integers(-1, 2, size=(9, 5, 5)).astype(np.int8)
+    pol, val = rng.dirichlet(np.ones(25), size=9), rng.choice([-1.0, 1.0], size=9)
+    full = save_examples_reference_format(str(tmp_path / "full.npz"), states, pol, val)
+    ref_like = str(tmp_path / "ref_like.npz")              # what the reference itself writes: boards / policies / values only
+    with zipfile.ZipFile(full) as zi, zipfile.ZipFile(ref_like, "w") as zo:
+        for name in ("boards.npy", "policies.npy", "values.npy"):
+            zo.writestr(name, zi.read(name))
+    with pytest.raises(ValueError, match="restricted unpickler"):
+        load_examples(ref_like)
+    ex = load_examples(ref_like, allow_reference_objects=True)
+    assert np.array_equal(ex["states"].numpy(), states) and np.allclose(ex["policies"].numpy(), pol.astype(np.float32))
+    q = TrainingDataQueue(max_size=100, sample_size=4)
+    q.push_file(ref_like, allow_reference_objects=True)
+    assert len(q) == 9
+    # a hostile stream: the object array's pickle names os.system -> refused, nothing executed
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    arr = np.empty(1, dtype=object)
+    arr[0] = Evil()
+    buf = io.BytesIO()
+    np.lib.format.write_array(buf, arr, allow_pickle=True)
+    hostile = str(tmp_path / "hostile.npz")
+    with zipfile.ZipFile(hostile, "w") as zo, zipfile.ZipFile(full) as zi:
+        zo.writestr("boards.npy", buf.getvalue())
+        zo.writestr("policies.npy", zi.read("policies.npy"))
+        zo.writestr("values.npy", zi.read("values.npy"))
+    with pytest.raises(pickle.UnpicklingError, match="refusing global"):
+        load_examples(hostile, allow_reference_objects=True)
+    assert not marker.exists()

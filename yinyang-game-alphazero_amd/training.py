@@ -12,6 +12,7 @@ Training itself is stock PyTorch-ROCm (out of the hot path).
 """
 import glob
 import os
+import pickle
 import random
 import time
 
@@ -145,10 +146,58 @@ def save_examples_reference_format(path, states, policies, values):
     return path
 
 
-def load_examples(path):
-    """Read a self_play_data_*.npz written by generate_self_play_data (plain arrays, no pickles)."""
+class _BoardUnpickler(pickle.Unpickler):
+    """Unpickler for the `boards` member of a reference-format data file.  It can build exactly three things: numpy arrays
+    (the array reconstructor, ndarray, dtype), and a plain attribute holder standing in for the reference's
+    `src.yin_yang.yin_yang_logic.YinYangLogic`.  Any other global in the stream -- i.e. anything that could run code --
+    raises UnpicklingError; nothing from the file is ever imported or called."""
+
+    class Board:
+        pass
+
+    _NUMPY = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+              ("numpy", "ndarray"), ("numpy", "dtype")}
+
+    def find_class(self, module, name):
+        if (module, name) == ("src.yin_yang.yin_yang_logic", "YinYangLogic"):
+            return _BoardUnpickler.Board
+        if (module, name) in self._NUMPY:
+            if name == "_reconstruct":      # numpy >= 2 keeps it in numpy._core, older releases in numpy.core
+                core = getattr(np, "_core", None) or __import__("numpy.core").core
+                return core.multiarray._reconstruct
+            return getattr(np, name)
+        raise pickle.UnpicklingError(f"refusing global {module}.{name} in a training-data file")
+
+
+def _load_reference_boards(path):
+    """The `boards` object array of a reference-format .npz -> int8 [N,R,C], through _BoardUnpickler only."""
+    import zipfile
+    with zipfile.ZipFile(path) as zf, zf.open("boards.npy") as fp:
+        version = np.lib.format.read_magic(fp)
+        shape, _, dtype = (np.lib.format.read_array_header_1_0 if version == (1, 0) else np.lib.format.read_array_header_2_0)(fp)
+        if not dtype.hasobject:
+            raise ValueError("boards is a plain array")
+        arr = _BoardUnpickler(fp).load()
+    boards = [np.asarray(b.board if isinstance(b, _BoardUnpickler.Board) else b, dtype=np.int8) for b in arr.reshape(-1)]
+    return np.stack(boards) if boards else np.zeros((0, 0, 0), np.int8)
+
+
+def load_examples(path, allow_reference_objects=False):
+    """Read a self_play_data_*.npz.  Files written by this package hold plain arrays and are read with allow_pickle=False.
+    A file in the reference's own format (self_play.py:374-384: `boards` = pickled board objects) is read only on request,
+    and then through a restricted unpickler that can construct numpy arrays and a plain stand-in for the board class and
+    nothing else (_BoardUnpickler) -- never with numpy's allow_pickle."""
     z = np.load(path, allow_pickle=False)
-    states = z["states"] if "states" in z.files else z["boards"]
+    if "states" in z.files:
+        states = z["states"]
+    else:
+        try:
+            states = z["boards"]
+        except ValueError:                       # object array
+            if not allow_reference_objects:
+                raise ValueError(f"{path} stores pickled board objects (the reference's format); pass "
+                                 "allow_reference_objects=True to read it through the restricted unpickler") from None
+            states = _load_reference_boards(path)
     return dict(states=torch.from_numpy(states.astype(np.int8)),
                 policies=torch.from_numpy(z["policies"].astype(np.float32)),
                 values=torch.from_numpy(z["values"].astype(np.float32)))
@@ -180,10 +229,10 @@ class TrainingDataQueue:
             k = len(self) - self.max_size
             self.states, self.policies, self.values = self.states[k:], self.policies[k:], self.values[k:]
 
-    def push_file(self, file_path):
+    def push_file(self, file_path, allow_reference_objects=False):
         if not os.path.exists(file_path):
             return
-        self.push_examples(load_examples(file_path))
+        self.push_examples(load_examples(file_path, allow_reference_objects))
 
     def sample(self, sample_size=None):
         n = len(self)
