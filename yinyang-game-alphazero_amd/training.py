@@ -415,8 +415,9 @@ class AlphaZeroTrainer:
 class TrainingPipeline:
     def __init__(self, game, model_dir="models", data_dir="data", lr=0.001, batch_size=64, weight_decay=1e-4,
                  epochs_per_iteration=10, sample_size=10000, queue_size=500000, checkpoint_interval=10,
-                 device=None, num_channels=128, num_res_blocks=10):
+                 device=None, num_channels=128, num_res_blocks=10, allow_reference_objects=False):
         self.game, self.model_dir, self.data_dir = game, model_dir, data_dir
+        self.allow_reference_objects = bool(allow_reference_objects)      # data files in the reference's pickled-board format
         self.epochs_per_iteration, self.sample_size, self.checkpoint_interval = epochs_per_iteration, sample_size, checkpoint_interval
         for d in (model_dir, data_dir):
             os.makedirs(d, exist_ok=True)
@@ -434,7 +435,7 @@ class TrainingPipeline:
 
     def load_data(self):
         for f in sorted(glob.glob(os.path.join(self.data_dir, "self_play_data_*.npz"))):
-            self.data_queue.push_file(f)
+            self.data_queue.push_file(f, self.allow_reference_objects)
 
     def train_iteration(self):
         ex = self.data_queue.sample()
