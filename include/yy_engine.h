@@ -178,7 +178,8 @@ int yy_nn_bias_act_bf16(void *x, const float *bias, const void *residual, int64_
  * [n_layers,128], both produced on the host from the module with eval-mode BatchNorm folded
  * (network.pack_tower).  n_layers = 1 + 2*res_blocks <= 21.  Boards 6x6, 8x8 or 12x12 (planes
  * [G,5,R,R], out [G,R,R,128]) and 128 channels; anything else returns YY_E_UNSUPPORTED and the
- * caller uses library convolutions + yy_nn_bias_act_bf16. */
+ * caller uses library convolutions + yy_nn_bias_act_bf16.  The launch picks the workgroup shape from G (8x8: one, two
+ * or four boards per workgroup, so that small batches still spread over the chip); a board's output bits do not depend on G. */
 int yy_nn_tower_bf16(const float *planes, const void *weights, const float *bias, void *out, int G,
                      int R, int C, int channels, int n_layers, yy_stream_t stream);
 
