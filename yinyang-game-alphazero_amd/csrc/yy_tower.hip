@@ -130,16 +130,48 @@ __device__ __forceinline__ void interleave_hint() {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);       // 5 MFMAs cover the last reads' latency
 }
-// cell geometry of a tap for this lane's two cells: LDS row base and swizzle key (zero row when off-board)
-__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int wave, int h, uint32_t (&cbase)[2]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+// Per-lane geometry of the lane's two cells (MFMA columns), computed ONCE per kernel: the LDS offset of the cell's own row
+// (+ this lane's h*16), a 9-bit mask of the taps whose neighbour is on the board, and the zero row.  The per-chunk tap
+// geometry is then four full-rate VALU ops per cell (and, compare, add a wave-uniform shift, select) instead of the
+// compare / multiply chain it used to re-derive inside the MFMA stream of every chunk.
+struct LaneGeo {
+    uint32_t rowbase[2], okmask[2], zbase;
+    int cy[2], cx, wave, h;   // only for the A/B build of the former per-chunk derivation (YY_TOWER_DEBUG=8)
+};
+__device__ __forceinline__ LaneGeo make_lane_geo(const int (&cy)[2], int cx, int wave, int h) {
+    LaneGeo g;
+    g.cy[0] = cy[0], g.cy[1] = cy[1], g.cx = cx, g.wave = wave, g.h = h;
+    g.zbase = (uint32_t)TW_ZERO_OFF + (uint32_t)(h * 16);
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
-        const int sy = cy[tt] + dy, sx = cx + dx;
-        const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
-        const int sc = sy * 8 + sx;
-        cbase[tt] = (ok ? (uint32_t)((wave * TW_CELLS + sc) * TW_ROW_BYTES) : (uint32_t)TW_ZERO_OFF) + (uint32_t)(h * 16);
+        g.rowbase[tt] = (uint32_t)((wave * TW_CELLS + cy[tt] * 8 + cx) * TW_ROW_BYTES) + (uint32_t)(h * 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int sy = cy[tt] + tap / 3 - 1, sx = cx + tap % 3 - 1;
+            if (((unsigned)sy < 8u) && ((unsigned)sx < 8u)) m |= 1u << tap;
+        }
+        g.okmask[tt] = m;
     }
+    return g;
+}
+// LDS row base of the tap's neighbour cell for this lane's two cells (the zero row when off-board); `tap` is wave-uniform
+template <int DBG>
+__device__ __forceinline__ void tap_geo(int tap, const LaneGeo &g, uint32_t (&cbase)[2]) {
+    if constexpr ((DBG & 8) != 0) {   // experiment: re-derive the geometry per chunk, as the kernel did before
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+            const int sy = g.cy[tt] + dy, sx = g.cx + dx;
+            const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
+            cbase[tt] = (ok ? (uint32_t)((g.wave * TW_CELLS + sy * 8 + sx) * TW_ROW_BYTES) : (uint32_t)TW_ZERO_OFF) + (uint32_t)(g.h * 16);
+        }
+        return;
+    }
+    const int shift = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * TW_ROW_BYTES;   // scalar unit
+    const uint32_t bit = 1u << tap;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) cbase[tt] = (g.okmask[tt] & bit) ? g.rowbase[tt] + (uint32_t)shift : g.zbase;
 }
 
 // One layer's chunks.  Invariant on entry and exit of every iteration: chunk `chunk` is visible in its
@@ -148,11 +180,10 @@ __device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int
 // across the chunk boundary too (only the first k-step of a layer exposes its read latency).
 template <int KS, int DBG>
 __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *lds, const unsigned char *weights, int &chunk,
-                                          int n_chunks, const int (&cy)[2], int cx, int wave, int lane) {
+                                          int n_chunks, const LaneGeo &geo, int wave, int lane) {
     constexpr int NCH = (KS == 1) ? 9 : 18;
-    const int h = lane >> 5;
     uint32_t cb[2];
-    tap_geo(0, cy, cx, wave, h, cb);
+    tap_geo<DBG>(0, geo, cb);
     Frags cur;
     load_frags(cur, lds, chunk % TW_NSLOT, 0, 0, cb, lane);
     for (int i = 0; i < NCH; i++, chunk++) {
@@ -171,7 +202,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][4], unsigned char *ld
         const bool last = (i == NCH - 1);
         uint32_t ncb[2];
         const int ni = last ? i : i + 1;
-        tap_geo((KS == 1) ? ni : (ni >> 1), cy, cx, wave, h, ncb);
+        tap_geo<DBG>((KS == 1) ? ni : (ni >> 1), geo, ncb);
         const int nhalf = (KS == 1) ? 0 : (ni & 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
@@ -231,13 +262,14 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
 
     // this lane's two cells (MFMA columns): tile 0 = board rows 0-3, tile 1 = rows 4-7
     const int cy[2] = {c >> 3, 4 + (c >> 3)}, cx = c & 7;
+    const LaneGeo geo = make_lane_geo(cy, cx, wave, h);
     uint32_t res[2][4][4][2];   // residual x, packed bf16 in the accumulator layout
     int chunk = 0;
 
     for (int L = 0; L < n_layers; L++) {
         f32x16 acc[2][4];
-        if (L == 0) run_layer<1, DBG>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
-        else run_layer<4, DBG>(acc, lds, weights, chunk, n_chunks, cy, cx, wave, lane);
+        if (L == 0) run_layer<1, DBG>(acc, lds, weights, chunk, n_chunks, geo, wave, lane);
+        else run_layer<4, DBG>(acc, lds, weights, chunk, n_chunks, geo, wave, lane);
         if constexpr ((DBG & 4) != 0) {   // experiment: no epilogue (keep the accumulators alive)
             asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]));
             asm volatile("" ::"v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]));
@@ -379,6 +411,7 @@ static int launch_tower(const float *planes, const void *weights, const float *b
         case 5: k_tower<5><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 6: k_tower<6><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 7: k_tower<7><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+        case 8: k_tower<8><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         default: k_tower<0><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
     }
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower: launch failed");

@@ -77,24 +77,40 @@ template <bool ZERO> __device__ __forceinline__ void mma16(f32x16 (&acc)[2][2], 
             for (int nt = 0; nt < 2; nt++)
                 acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[nt][s], f.x[tt][s], (ZERO && s == 0) ? z : acc[tt][nt], 0, 0, 0);
 }
-__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int board, int h, uint32_t (&cbase)[2]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+// per-lane geometry, computed once per kernel: own row offsets (+ h*16), on-board tap mask, zero row
+struct LaneGeo {
+    uint32_t rowbase[2], okmask[2], zbase;
+};
+__device__ __forceinline__ LaneGeo make_lane_geo(const int (&cy)[2], int cx, int board, int h) {
+    LaneGeo g;
+    g.zbase = (uint32_t)F_ZERO_OFF + (uint32_t)(h * 16);
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
-        const int sy = cy[tt] + dy, sx = cx + dx;
-        const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
-        cbase[tt] = (ok ? (uint32_t)((board * F_CELLS + sy * 8 + sx) * F_ROW_BYTES) : (uint32_t)F_ZERO_OFF) + (uint32_t)(h * 16);
+        g.rowbase[tt] = (uint32_t)((board * F_CELLS + cy[tt] * 8 + cx) * F_ROW_BYTES) + (uint32_t)(h * 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int sy = cy[tt] + tap / 3 - 1, sx = cx + tap % 3 - 1;
+            if (((unsigned)sy < 8u) && ((unsigned)sx < 8u)) m |= 1u << tap;
+        }
+        g.okmask[tt] = m;
     }
+    return g;
+}
+__device__ __forceinline__ void tap_geo(int tap, const LaneGeo &g, uint32_t (&cbase)[2]) {
+    const int shift = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * F_ROW_BYTES;   // wave-uniform
+    const uint32_t bit = 1u << tap;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) cbase[tt] = (g.okmask[tt] & bit) ? g.rowbase[tt] + (uint32_t)shift : g.zbase;
 }
 
 // A layer = 9 taps x Q quarter-chunks (Q = 4; stem: 1 chunk per tap, only its first m-block is non-zero / computed).
 template <bool STEM>
 __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][2], unsigned char *lds, const unsigned char *weights, int &chunk,
-                                          int n_chunks, const int (&cy)[2], int cx, int board, int nh, int wave, int lane) {
+                                          int n_chunks, const LaneGeo &geo, int nh, int wave, int lane) {
     constexpr int Q = STEM ? 1 : 4, MB = STEM ? 1 : 4, NCH = 9 * Q;
-    const int h = lane >> 5;
     uint32_t cb[2];
-    tap_geo(0, cy, cx, board, h, cb);
+    tap_geo(0, geo, cb);
     Frags cur;
     for (int i = 0; i < NCH; i++, chunk++) {
         const int quarter = STEM ? 0 : (i & 3);
@@ -115,7 +131,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][2], unsigned char *ld
         const bool last = (i == NCH - 1);
         const int ni = last ? i : i + 1;
         uint32_t ncb[2];
-        tap_geo(STEM ? ni : (ni >> 2), cy, cx, board, h, ncb);
+        tap_geo(STEM ? ni : (ni >> 2), geo, ncb);
         const int nquarter = STEM ? 0 : (ni & 3);
         const bool next_tap = STEM || (quarter == 3);
 #pragma unroll
@@ -164,12 +180,13 @@ k_tower_f32(const float *__restrict__ planes, const unsigned char *__restrict__ 
     else wait_vmcnt<0>();
 
     const int cy[2] = {c >> 3, 4 + (c >> 3)}, cx = c & 7;
+    const LaneGeo geo = make_lane_geo(cy, cx, board, h);
     f32x4 res[2][2][4];   // residual x of this wave's 64 couts, exact f32
     int chunk = 0;
     for (int L = 0; L < n_layers; L++) {
         f32x16 acc[2][2];
-        if (L == 0) run_layer<true>(acc, lds, weights, chunk, n_chunks, cy, cx, board, nh, wave, lane);
-        else run_layer<false>(acc, lds, weights, chunk, n_chunks, cy, cx, board, nh, wave, lane);
+        if (L == 0) run_layer<true>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
+        else run_layer<false>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave has finished reading this layer's input
         asm volatile("" ::: "memory");

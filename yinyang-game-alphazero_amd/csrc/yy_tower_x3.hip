@@ -106,14 +106,34 @@ template <bool ZERO> __device__ __forceinline__ void mma12(f32x16 (&acc)[2][2], 
             acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wh[nt], f.xh[tt], a, 0, 0, 0);
         }
 }
-__device__ __forceinline__ void tap_geo(int tap, const int (&cy)[2], int cx, int board, int h, Bases &cbase) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+// per-lane geometry, computed once per kernel: own rows (hi part; the lo part sits 64 rows further), on-board tap mask
+struct LaneGeo {
+    uint32_t rowbase[2], okmask[2], zbase;
+};
+__device__ __forceinline__ LaneGeo make_lane_geo(const int (&cy)[2], int cx, int board, int h) {
+    LaneGeo g;
+    g.zbase = (uint32_t)X_ZERO_OFF + (uint32_t)(h * 16);
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
-        const int sy = cy[tt] + dy, sx = cx + dx;
-        const bool ok = ((unsigned)sy < 8u) && ((unsigned)sx < 8u);
-        cbase.hi[tt] = (ok ? row_off(board, 0, sy * 8 + sx) : (uint32_t)X_ZERO_OFF) + (uint32_t)(h * 16);
-        cbase.lo[tt] = (ok ? row_off(board, 1, sy * 8 + sx) : (uint32_t)X_ZERO_OFF) + (uint32_t)(h * 16);
+        g.rowbase[tt] = row_off(board, 0, cy[tt] * 8 + cx) + (uint32_t)(h * 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int sy = cy[tt] + tap / 3 - 1, sx = cx + tap % 3 - 1;
+            if (((unsigned)sy < 8u) && ((unsigned)sx < 8u)) m |= 1u << tap;
+        }
+        g.okmask[tt] = m;
+    }
+    return g;
+}
+__device__ __forceinline__ void tap_geo(int tap, const LaneGeo &g, Bases &cbase) {
+    const int shift = ((tap / 3 - 1) * 8 + (tap % 3 - 1)) * X_ROW_BYTES;   // wave-uniform
+    const uint32_t bit = 1u << tap;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+        const bool ok = (g.okmask[tt] & bit) != 0;
+        cbase.hi[tt] = ok ? g.rowbase[tt] + (uint32_t)shift : g.zbase;
+        cbase.lo[tt] = ok ? g.rowbase[tt] + (uint32_t)(shift + X_CELLS * X_ROW_BYTES) : g.zbase;
     }
 }
 // the 8 reads of the next k-step inside the 12 MFMAs of this one
@@ -129,11 +149,10 @@ __device__ __forceinline__ void interleave_hint() {
 // A layer = 9 taps x Q quarter-chunks (Q = 4, two k-steps each; stem: 1 chunk per tap, one k-step = 16 padded channels).
 template <bool STEM>
 __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][2], unsigned char *lds, const unsigned char *weights, int &chunk,
-                                          int n_chunks, const int (&cy)[2], int cx, int board, int nh, int wave, int lane) {
+                                          int n_chunks, const LaneGeo &geo, int nh, int wave, int lane) {
     constexpr int Q = STEM ? 1 : 4, KS = STEM ? 1 : 2, NCH = 9 * Q;
-    const int h = lane >> 5;
     Bases cb;
-    tap_geo(0, cy, cx, board, h, cb);
+    tap_geo(0, geo, cb);
     Frags cur;
     for (int i = 0; i < NCH; i++, chunk++) {
         const int quarter = STEM ? 0 : (i & 3);
@@ -154,7 +173,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[2][2], unsigned char *ld
         const bool last = (i == NCH - 1);
         const int ni = last ? i : i + 1;
         Bases ncb;
-        tap_geo(STEM ? ni : (ni >> 2), cy, cx, board, h, ncb);
+        tap_geo(STEM ? ni : (ni >> 2), geo, ncb);
         const int nquarter = STEM ? 0 : (ni & 3);
         const bool next_tap = STEM || (quarter == 3);
 #pragma unroll
@@ -206,12 +225,13 @@ k_tower_x3(const float *__restrict__ planes, const unsigned char *__restrict__ w
     else wait_vmcnt<0>();
 
     const int cy[2] = {c >> 3, 4 + (c >> 3)}, cx = c & 7;
+    const LaneGeo geo = make_lane_geo(cy, cx, board, h);
     f32x4 res[2][2][4];   // residual x of this wave's 64 couts, f32
     int chunk = 0;
     for (int L = 0; L < n_layers; L++) {
         f32x16 acc[2][2];
-        if (L == 0) run_layer<true>(acc, lds, weights, chunk, n_chunks, cy, cx, board, nh, wave, lane);
-        else run_layer<false>(acc, lds, weights, chunk, n_chunks, cy, cx, board, nh, wave, lane);
+        if (L == 0) run_layer<true>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
+        else run_layer<false>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave has finished reading this layer's input
         asm volatile("" ::: "memory");

@@ -114,27 +114,44 @@ template <int CT> __device__ __forceinline__ void interleave_hint() {
     }
     if (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
 }
-// this lane's column in tile tt is col = tt*32 + c = board*CELLS + cell; its tap neighbour is column col + dy*R + dx
+// Per-lane geometry, computed once per kernel: this lane's column in tile tt is col = tt*32 + c = board*CELLS + cell, its
+// tap neighbour is column col + dy*R + dx.  rowbase = LDS offset of the column's own row (+ h*16), okmask = 9-bit mask of the
+// taps whose neighbour is on the board.  The per-chunk tap geometry is then an and / compare / add / select per tile.
+template <class GEO> struct LaneGeo {
+    uint32_t rowbase[GEO::CT], okmask[GEO::CT], zbase;
+};
 template <class GEO>
-__device__ __forceinline__ void tap_geo(int tap, int c, int h, uint32_t (&cbase)[GEO::CT]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+__device__ __forceinline__ void make_lane_geo(LaneGeo<GEO> &g, int c, int h) {
+    g.zbase = (uint32_t)GEO::ZERO_OFF + (uint32_t)(h * 16);
 #pragma unroll
     for (int tt = 0; tt < GEO::CT; tt++) {
         const int col = tt * 32 + c;
         const int cell = col % GEO::CELLS;
         const int y = cell / GEO::R, x = cell - y * GEO::R;
-        const bool ok = ((unsigned)(y + dy) < (unsigned)GEO::R) && ((unsigned)(x + dx) < (unsigned)GEO::R);
-        cbase[tt] = (ok ? (uint32_t)((col + dy * GEO::R + dx) * TQ_ROW_BYTES) : (uint32_t)GEO::ZERO_OFF) + (uint32_t)(h * 16);
+        g.rowbase[tt] = (uint32_t)(col * TQ_ROW_BYTES) + (uint32_t)(h * 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
+            if (((unsigned)sy < (unsigned)GEO::R) && ((unsigned)sx < (unsigned)GEO::R)) m |= 1u << tap;
+        }
+        g.okmask[tt] = m;
     }
+}
+template <class GEO>
+__device__ __forceinline__ void tap_geo(int tap, const LaneGeo<GEO> &g, uint32_t (&cbase)[GEO::CT]) {
+    const int shift = ((tap / 3 - 1) * GEO::R + (tap % 3 - 1)) * TQ_ROW_BYTES;   // wave-uniform
+    const uint32_t bit = 1u << tap;
+#pragma unroll
+    for (int tt = 0; tt < GEO::CT; tt++) cbase[tt] = (g.okmask[tt] & bit) ? g.rowbase[tt] + (uint32_t)shift : g.zbase;
 }
 
 template <class GEO, int KS>
 __device__ __forceinline__ void run_layer(f32x16 (&acc)[GEO::CT], unsigned char *lds, const unsigned char *weights, int &chunk,
-                                          int n_chunks, int c, int nh, int wave, int lane) {
+                                          int n_chunks, const LaneGeo<GEO> &geo, int nh, int wave, int lane) {
     constexpr int NCH = (KS == 1) ? 9 : 18, CT = GEO::CT;
-    const int h = lane >> 5;
     uint32_t cb[CT];
-    tap_geo<GEO>(0, c, h, cb);
+    tap_geo<GEO>(0, geo, cb);
     Frags<CT> cur;
     for (int i = 0; i < NCH; i++, chunk++) {
         const int half = (KS == 1) ? 0 : (i & 1);
@@ -153,7 +170,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[GEO::CT], unsigned char 
         const bool last = (i == NCH - 1);
         uint32_t ncb[CT];
         const int ni = last ? i : i + 1;
-        tap_geo<GEO>((KS == 1) ? ni : (ni >> 1), c, h, ncb);
+        tap_geo<GEO>((KS == 1) ? ni : (ni >> 1), geo, ncb);
         const int nhalf = (KS == 1) ? 0 : (ni & 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
@@ -208,12 +225,14 @@ k_towerq(const float *__restrict__ planes, const unsigned char *__restrict__ wei
     if (n_chunks >= 3) wait_vmcnt<8>();
     else wait_vmcnt<0>();
 
+    LaneGeo<GEO> geo;
+    make_lane_geo<GEO>(geo, c, h);
     uint32_t res[CT][4][2];
     int chunk = 0;
     for (int L = 0; L < n_layers; L++) {
         f32x16 acc[CT];
-        if (L == 0) run_layer<GEO, 1>(acc, lds, weights, chunk, n_chunks, c, nh, wave, lane);
-        else run_layer<GEO, 4>(acc, lds, weights, chunk, n_chunks, c, nh, wave, lane);
+        if (L == 0) run_layer<GEO, 1>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
+        else run_layer<GEO, 4>(acc, lds, weights, chunk, n_chunks, geo, nh, wave, lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave has finished reading this layer's input
         asm volatile("" ::: "memory");
