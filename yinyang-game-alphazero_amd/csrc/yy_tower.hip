@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/yy_engine.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -276,34 +278,53 @@ k_tower(const float *__restrict__ planes, const unsigned char *__restrict__ weig
             continue;
         }
         // ---- epilogue (wave-private: a wave reads and writes only its own board's cells):
-        // + bias (+ residual), bf16 rounding, ReLU on the packed pair (v_pk_max_i16: bf16 is sign-magnitude)
+        // + bias (+ residual), bf16 rounding, ReLU on the packed pair (v_pk_max_i16: bf16 is sign-magnitude).
+        // No MFMA runs here, so every stall is paid in full: the 16 bias vectors of this lane are fetched in two batches of
+        // 8 back-to-back reads (one LDS latency each batch instead of one per vector), the pair conversion is ONE
+        // v_cvt_pk_bf16_f32 (vector convert), and the residual branch is resolved once per layer.
         const bool conv2 = (L >= 2) && ((L & 1) == 0);   // second conv of a block: + residual
         const bool keep = (L == 0) || conv2;             // output is a block input x: keep it for the skip
+        const unsigned char *bl = lds + TW_BIAS_OFF + (L * TW_CH + 4 * h) * 4;
+        auto epilogue_half = [&](const int nt0, auto with_res) {
+            constexpr bool RES = decltype(with_res)::value;
+            f32x4 b[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+            for (int n2 = 0; n2 < 2; n2++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                // this lane's rows of tile nt are couts nt*32 + 8q + 4h + i
-                const f32x4 b = *(const f32x4 *)(lds + TW_BIAS_OFF + (L * TW_CH + nt * 32 + 8 * q + 4 * h) * 4);
+                for (int q = 0; q < 4; q++) b[n2][q] = *(const f32x4 *)(bl + ((nt0 + n2) * 32 + 8 * q) * 4);
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
-                    f32x2 v01 = {acc[tt][nt][4 * q + 0] + b[0], acc[tt][nt][4 * q + 1] + b[1]};
-                    f32x2 v23 = {acc[tt][nt][4 * q + 2] + b[2], acc[tt][nt][4 * q + 3] + b[3]};
-                    if (conv2) {
-                        const uint32_t r0 = res[tt][nt][q][0], r1 = res[tt][nt][q][1];
-                        v01 += (f32x2){bf_lo(r0), bf_hi(r0)};
-                        v23 += (f32x2){bf_lo(r1), bf_hi(r1)};
+            for (int n2 = 0; n2 < 2; n2++) {
+                const int nt = nt0 + n2;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        // this lane's rows of tile nt are couts nt*32 + 8q + 4h + i
+                        f32x2 v01 = {acc[tt][nt][4 * q + 0] + b[n2][q][0], acc[tt][nt][4 * q + 1] + b[n2][q][1]};
+                        f32x2 v23 = {acc[tt][nt][4 * q + 2] + b[n2][q][2], acc[tt][nt][4 * q + 3] + b[n2][q][3]};
+                        if (RES) {
+                            const uint32_t r0 = res[tt][nt][q][0], r1 = res[tt][nt][q][1];
+                            v01 += (f32x2){bf_lo(r0), bf_hi(r0)};
+                            v23 += (f32x2){bf_lo(r1), bf_hi(r1)};
+                        }
+                        const uint32_t p0 = relu_pk(__builtin_bit_cast(uint32_t, __builtin_convertvector(v01, bf16x2)));
+                        const uint32_t p1 = relu_pk(__builtin_bit_cast(uint32_t, __builtin_convertvector(v23, bf16x2)));
+                        if (keep) {
+                            res[tt][nt][q][0] = p0;
+                            res[tt][nt][q][1] = p1;
+                        }
+                        u32x2 pk = {p0, p1};
+                        *(u32x2 *)(lds + act_off(wave, tt * 32 + c, nt * 4 + q) + h * 8) = pk;
                     }
-                    const uint32_t p0 = relu_pk(pack_bf16(v01[0], v01[1]));
-                    const uint32_t p1 = relu_pk(pack_bf16(v23[0], v23[1]));
-                    if (keep) {
-                        res[tt][nt][q][0] = p0;
-                        res[tt][nt][q][1] = p1;
-                    }
-                    u32x2 pk = {p0, p1};
-                    *(u32x2 *)(lds + act_off(wave, tt * 32 + c, nt * 4 + q) + h * 8) = pk;
-                }
             }
+        };
+        if (conv2) {
+            epilogue_half(0, std::true_type{});
+            epilogue_half(2, std::true_type{});
+        } else {
+            epilogue_half(0, std::false_type{});
+            epilogue_half(2, std::false_type{});
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (out_heads) {
