@@ -192,12 +192,19 @@ k_tower_f32(const float *__restrict__ planes, const unsigned char *__restrict__ 
         asm volatile("" ::: "memory");
         const bool conv2 = (L >= 2) && ((L & 1) == 0);
         const bool keep = (L == 0) || conv2;
+        // the lane's 8 bias vectors in one batch of back-to-back reads (no MFMA runs here: every stall is paid in full)
+        f32x4 bq[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                bq[nt][q] = *(const f32x4 *)(lds + F_BIAS_OFF + (L * F_CH + (nh * 2 + nt) * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int co = (nh * 2 + nt) * 32 + 8 * q + 4 * h;   // this lane's 4 couts (accumulator rows 4q..4q+3)
-                const f32x4 b = *(const f32x4 *)(lds + F_BIAS_OFF + (L * F_CH + co) * 4);
+                const f32x4 b = bq[nt][q];
 #pragma unroll
                 for (int tt = 0; tt < 2; tt++) {
                     f32x4 v = {acc[tt][nt][4 * q + 0] + b[0], acc[tt][nt][4 * q + 1] + b[1],

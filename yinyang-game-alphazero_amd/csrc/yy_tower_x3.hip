@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -237,12 +238,19 @@ k_tower_x3(const float *__restrict__ planes, const unsigned char *__restrict__ w
         asm volatile("" ::: "memory");
         const bool conv2 = (L >= 2) && ((L & 1) == 0);
         const bool keep = (L == 0) || conv2;
+        // the lane's 8 bias vectors in one batch of back-to-back reads (no MFMA runs here: every stall is paid in full)
+        f32x4 bq[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                bq[nt][q] = *(const f32x4 *)(lds + X_BIAS_OFF + (L * X_CH + (nh * 2 + nt) * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int co = (nh * 2 + nt) * 32 + 8 * q + 4 * h;   // this lane's 4 couts (accumulator rows 4q..4q+3)
-                const f32x4 b = *(const f32x4 *)(lds + X_BIAS_OFF + (L * X_CH + co) * 4);
+                const f32x4 b = bq[nt][q];
 #pragma unroll
                 for (int tt = 0; tt < 2; tt++) {
                     f32x4 v = {acc[tt][nt][4 * q + 0] + b[0], acc[tt][nt][4 * q + 1] + b[1],
@@ -251,12 +259,14 @@ k_tower_x3(const float *__restrict__ planes, const unsigned char *__restrict__ w
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.0f);
                     if (keep) res[tt][nt][q] = v;
-                    uint32_t hi[4], lo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) split_bf16(v[i], hi[i], lo[i]);
+                    // (hi, lo) split, two values per packed convert: hi = bf16(v), lo = bf16(v - hi)
+                    const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+                    const bf16x2 h01 = __builtin_convertvector(a01, bf16x2), h23 = __builtin_convertvector(a23, bf16x2);
+                    const f32x2 r01 = a01 - __builtin_convertvector(h01, f32x2), r23 = a23 - __builtin_convertvector(h23, f32x2);
+                    const bf16x2 l01 = __builtin_convertvector(r01, bf16x2), l23 = __builtin_convertvector(r23, bf16x2);
                     const int cell = tt * 32 + c;
-                    const u32x2 ph = {hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
-                    const u32x2 pl = {lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
+                    const u32x2 ph = {__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)};
+                    const u32x2 pl = {__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)};
                     *(u32x2 *)(lds + row_off(board, 0, cell) + co * 2) = ph;
                     *(u32x2 *)(lds + row_off(board, 1, cell) + co * 2) = pl;
                 }

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/yy_engine.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -238,29 +240,39 @@ k_towerq(const float *__restrict__ planes, const unsigned char *__restrict__ wei
         asm volatile("" ::: "memory");
         const bool conv2 = (L >= 2) && ((L & 1) == 0);
         const bool keep = (L == 0) || conv2;
+        // no MFMA runs in the epilogue, so stalls are paid in full: the lane's four bias vectors are fetched back to back
+        // (one LDS latency), the pair conversion is one v_cvt_pk_bf16_f32, the residual branch is resolved once per layer
+        f32x4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int co = nh * 32 + 8 * q + 4 * h;       // this lane's 4 couts
-            const f32x4 b = *(const f32x4 *)(lds + GEO::BIAS_OFF + (L * TQ_CH + co) * 4);
+        for (int q = 0; q < 4; q++) bq[q] = *(const f32x4 *)(lds + GEO::BIAS_OFF + (L * TQ_CH + nh * 32 + 8 * q + 4 * h) * 4);
+        auto epilogue = [&](auto with_res) {
+            constexpr bool RES = decltype(with_res)::value;
 #pragma unroll
-            for (int tt = 0; tt < CT; tt++) {
-                f32x2 v01 = {acc[tt][4 * q + 0] + b[0], acc[tt][4 * q + 1] + b[1]};
-                f32x2 v23 = {acc[tt][4 * q + 2] + b[2], acc[tt][4 * q + 3] + b[3]};
-                if (conv2) {
-                    const uint32_t r0 = res[tt][q][0], r1 = res[tt][q][1];
-                    v01 += (f32x2){bf_lo(r0), bf_hi(r0)};
-                    v23 += (f32x2){bf_lo(r1), bf_hi(r1)};
+            for (int q = 0; q < 4; q++) {
+                const int co = nh * 32 + 8 * q + 4 * h;       // this lane's 4 couts
+                const f32x4 b = bq[q];
+#pragma unroll
+                for (int tt = 0; tt < CT; tt++) {
+                    f32x2 v01 = {acc[tt][4 * q + 0] + b[0], acc[tt][4 * q + 1] + b[1]};
+                    f32x2 v23 = {acc[tt][4 * q + 2] + b[2], acc[tt][4 * q + 3] + b[3]};
+                    if (RES) {
+                        const uint32_t r0 = res[tt][q][0], r1 = res[tt][q][1];
+                        v01 += (f32x2){bf_lo(r0), bf_hi(r0)};
+                        v23 += (f32x2){bf_lo(r1), bf_hi(r1)};
+                    }
+                    const uint32_t p0 = relu_pk(__builtin_bit_cast(uint32_t, __builtin_convertvector(v01, bf16x2)));
+                    const uint32_t p1 = relu_pk(__builtin_bit_cast(uint32_t, __builtin_convertvector(v23, bf16x2)));
+                    if (keep) {
+                        res[tt][q][0] = p0;
+                        res[tt][q][1] = p1;
+                    }
+                    u32x2 pk = {p0, p1};
+                    *(u32x2 *)(lds + act_off(tt * 32 + c, co >> 3) + (co & 4) * 2) = pk;
                 }
-                const uint32_t p0 = relu_pk(pack_bf16(v01[0], v01[1]));
-                const uint32_t p1 = relu_pk(pack_bf16(v23[0], v23[1]));
-                if (keep) {
-                    res[tt][q][0] = p0;
-                    res[tt][q][1] = p1;
-                }
-                u32x2 pk = {p0, p1};
-                *(u32x2 *)(lds + act_off(tt * 32 + c, co >> 3) + (co & 4) * 2) = pk;
             }
-        }
+        };
+        if (conv2) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
