@@ -156,7 +156,9 @@ int yy_mcts_root_stats(yy_mcts *ctx, int32_t *visits, double *value_sum, yy_stre
  * the mutated caller board in aliased mode. */
 int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
 
-/* sync. Host outputs: number of games whose arena overflowed (they stop searching), and
+/* sync. Host outputs: number of games that failed in ANY search since the previous status call -- arena overflow,
+ * NaN priors or a NaN value from the evaluator; such a game stops searching, and the flag is sticky: yy_mcts_begin
+ * does not clear it, only this call does -- and
  * counters[8] = {evaluator rows requested, selection levels walked, children scanned during
  * selection, children created, terminal revisits, nodes created, 0, 0} accumulated since create
  * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
@@ -212,6 +214,35 @@ int yy_nn_tower_bf16x3(const float *planes, const void *weights, const float *bi
  * tanh(relu(hidden) . w2 + b2) with w2 float32 [H], b2 float32 [1]. */
 int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2,
                            float *policy, float *value, yy_stream_t stream);
+
+/* The residual tower at FLOAT32 accuracy on the F16 matrix cores ("split-f16"): activations and weights are held as
+ * hi = f16(x), lo = f16((x - hi) * 2^11) (22 significant bits), each product is w_hi*x_hi + 2^-11 * (w_hi*x_lo + w_lo*x_hi)
+ * on v_mfma_f32_32x32x16_f16 into two f32 accumulators; bias / residual / ReLU in f32.  Agrees with a float64 evaluation
+ * to ~4e-7 of scale, like the float32 module itself.  Same I/O as yy_nn_tower_f32; weights = f16 chunks
+ * [9 + 36*(n_layers-1)][8192] from network.pack_tower_h3.  Boards 8x8 (two boards per workgroup), 6x6 and 12x12
+ * (yy_tower_h3q.hip), 128 channels.  Replaces ai/neural_network.py:94-110 (float32 on the CPU in the reference). */
+int yy_nn_tower_f16x3(const float *planes, const void *weights, const float *bias, float *out, int G,
+                      int R, int C, int channels, int n_layers, yy_stream_t stream);
+
+/* Same kernel + the policy_conv / value_conv 1x1 head convolutions, BatchNorm and ReLU (neural_network.py:113, 118):
+ * out_heads float32 [G,2,32,R*R] = [policy features, value features] in the reference's NCHW flatten order (:114 / :119).
+ * weights holds two more chunks and bias one more row (network.pack_heads_h3).  rows / n_rows (device pointers, or both
+ * NULL): evaluate planes[rows[i]] for i < *n_rows into out_heads row i; workgroups past *n_rows exit at once. */
+int yy_nn_tower_heads_f16x3(const float *planes, const void *weights, const float *bias, float *out_heads,
+                            const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
+                            int channels, int n_layers, yy_stream_t stream);
+
+/* float32 head finish (neural_network.py:115, 120-121, 152): logits float32 [G,A] (policy_fc output, bias added), hidden
+ * float32 [G,H] (value_fc1 output, bias added) of dense row i -> policy[g] = softmax(logits[i]),
+ * value[g] = tanh(relu(hidden[i]) . w2 + b2), g = rows ? rows[i] : i, for i < (n_rows ? *n_rows : G). */
+int yy_nn_head_finish_f32(const float *logits, const float *hidden, int G, int A, int H, const float *w2,
+                          const float *b2, const int32_t *rows, const int32_t *n_rows, float *policy,
+                          float *value, yy_stream_t stream);
+
+/* Leaf-batch compaction for the lockstep step: rows[0 .. *n) = ascending indices g < G with flags[g] != 0 (the games whose
+ * selected leaf needs an evaluation: yy_mcts_select / yy_mcts_step write these flags; a terminal revisit does not,
+ * mcts.py:365-366).  All pointers are device pointers. */
+int yy_compact_rows(const uint8_t *flags, int G, int32_t *rows, int32_t *n, yy_stream_t stream);
 
 #ifdef __cplusplus
 }

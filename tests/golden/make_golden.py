@@ -402,6 +402,32 @@ def gen_g3_net(pool):
     print("wrote", path, flush=True)
 
 
+def _search_net800_case(args):
+    """One 800-simulation search with the real seeded 128x10 net (CPU fp32, as the reference runs it): only the RESULTS are
+    kept (pi, counts, child statistics, root value sum, the root evaluation) -- the live GPU evaluators are compared with these."""
+    R, C, seed, sims, copied, noise, root_player = args
+    r = _search_net_case((R, C, seed, sims, copied, noise)) if root_player == 1 else None
+    assert r is not None
+    out = {k: v for k, v in r.items() if not k.startswith("rec_")}
+    out["root_policy"] = r["rec_policy"][0]
+    out["root_value"] = r["rec_value"][0]
+    out["n_evals"] = np.int32(r["rec_policy"].shape[0] - 1)
+    out["seed"] = np.int32(seed)
+    return out
+
+
+def gen_g3_net800(pool):
+    """search_net800_8x8.npz: 64 roots (empty board and random legal-play positions) x 800 simulations, both board semantics,
+    with and without root noise (real-net part; ai/mcts.py:275-343 with ai/neural_network.py:125-154)."""
+    R = C = 8
+    jobs = [(R, C, 2000 + k, 800, k % 2, (k // 2) % 2, 1) for k in range(64)]
+    res = pool.map(_search_net800_case, jobs, chunksize=1)
+    out = {k: np.stack([np.asarray(r[k]) for r in res]) for k in res[0]}
+    path = os.path.join(OUT, "search_net800_8x8.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(res), "cases", flush=True)
+
+
 # --------------------------------------------------------------------------- G4
 def _episode_case(args):
     R, C, seed, sims, copied, pbits, vbits = args
@@ -591,6 +617,8 @@ def main():
         gen_g3([(3, 3), (4, 4), (6, 6), (8, 8), (12, 12), (5, 7)], pool)
     if "g3net" in only:
         gen_g3_net(pool)
+    if "g3net800" in only:
+        gen_g3_net800(pool)
     if "g4" in only:
         gen_g4(pool)
     if "g6" in only:

@@ -283,6 +283,98 @@ def test_gpu_evaluators_against_reference_recorded_outputs():
     boards = torch.from_numpy(z["rec_boards"][1, :n]).cuda()
     rp, rv = torch.from_numpy(z["rec_policy"][1, :n]).cuda(), torch.from_numpy(z["rec_value"][1, :n]).cuda()
     planes = pkg.engine.encode_planes(boards)
-    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
+    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("f16x3", 1e-5, 1e-5), ("bf16x3", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
         p, v = pkg.BatchedEvaluator(net, mode)(planes)
-        assert float((p - rp).abs().max()) < tp and float((v - rv).abs().max()) < tv, mode
+        ep, ev_ = float((p - rp).abs().max()), float((v - rv).abs().max())
+        print("%s vs the reference's recorded outputs: policy %.3e value %.3e" % (mode, ep, ev_))
+        assert ep < tp and ev_ < tv, mode
+
+
+def _randomized_net(pkg, game, blocks, seed):
+    import torch
+    torch.manual_seed(seed)
+    net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.7, 1.3)
+                m.bias.normal_(0, 0.1)
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.normal_(0, 0.05)
+    return net
+
+
+def _module_f64(net, planes):
+    """The module in float64 on the device (native torch convolutions): the reference point both the float32 module and
+    the split-f16 kernel are measured against."""
+    import copy
+    import torch
+    n64 = copy.deepcopy(net).double().eval()
+    with torch.no_grad():
+        x = torch.relu(n64.bn1(n64.conv1(planes.double())))
+        for blk in n64.res_blocks:
+            x = blk(x)
+        logits, value = n64(planes.double())
+        return x, torch.softmax(logits, 1), value.reshape(-1)
+
+
+@pytest.mark.parametrize("R", [8])
+def test_split_f16_tower_kernel_is_float32_grade(R):
+    """csrc/yy_tower_h3.hip (activations and weights as hi + lo*2^-11 float16 pairs, three f16 MFMAs per product term, two
+    f32 accumulators) against the module evaluated in FLOAT64: 22 significant bits per operand, so the error must be that
+    of float32 arithmetic itself.  Bounds: tower activations within 2e-6 of the layer scale (measured ~4e-7; the float32
+    module measures ~3e-7 on the same inputs), policy and value within 2e-6 abs (north-star: 1e-5)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    torch.backends.cudnn.allow_tf32 = False
+    game = pkg.YinYangGame(R, R)
+    rng = np.random.default_rng(6)
+    for blocks, G in ((1, 3), (10, 71)):
+        net = _randomized_net(pkg, game, blocks, 2)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        ev = pkg.BatchedEvaluator(net, "f16x3")
+        n_tower = 9 + 36 * (ev.h3_layers - 1)
+        x_t = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), ev.h3_b[:ev.h3_layers].contiguous(), ev.h3_layers)
+        x64, p64, v64 = _module_f64(net, planes)
+        scale = float(x64.abs().max())
+        err = float((x_t.double() - x64).abs().max())
+        with torch.no_grad():
+            x32 = torch.relu(net.bn1(net.conv1(planes)))
+            for blk in net.res_blocks:
+                x32 = blk(x32)
+        err32 = float((x32.double() - x64).abs().max())
+        print("f16x3 tower %dx%d: blocks %d max|err| %.3e (fp32 module %.3e) scale %.3e" % (R, R, blocks, err, err32, scale))
+        assert err <= 2e-6 * scale, (blocks, err, scale)
+        p, v = ev(planes)
+        ep, evv = float((p.double() - p64).abs().max()), float((v.double() - v64).abs().max())
+        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
+        print("f16x3 evaluator: policy err %.3e value err %.3e (fp32 module: %.3e / %.3e)" % (
+            ep, evv, float((p32.double() - p64).abs().max()), float((v32.double() - v64).abs().max())))
+        assert ep < 2e-6 and evv < 2e-6
+        assert torch.allclose(p.sum(1), torch.ones(G, device="cuda"), atol=1e-5)
+
+
+def test_split_f16_evaluator_row_compaction_is_bit_exact():
+    """evaluator(planes, needs_eval): the flagged rows hold exactly the bits of the full evaluation (a board's output does
+    not depend on the workgroup / row it is evaluated in), the other rows are zero; every pattern incl. none and all."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(8, 8)
+    net = _randomized_net(pkg, game, 2, 3)
+    ev = pkg.BatchedEvaluator(net, "f16x3")
+    rng = np.random.default_rng(9)
+    for G in (1, 2, 5, 64, 333):
+        planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
+        p_all, v_all = ev(planes)
+        for frac in (0.0, 0.5, 0.94, 1.0):
+            flags = torch.from_numpy((rng.random(G) < frac).astype(np.uint8)).cuda()
+            rows, n = pkg.engine.compact_rows(flags)
+            idx = flags.nonzero(as_tuple=True)[0]
+            assert int(n) == idx.numel() and torch.equal(rows[: int(n)].long(), idx)
+            p, v = ev(planes, needs_eval=flags)
+            keep = flags.bool()
+            assert torch.equal(p[keep], p_all[keep]) and torch.equal(v[keep], v_all[keep])
+            assert float(p[~keep].abs().sum()) == 0.0 and float(v[~keep].abs().sum()) == 0.0

@@ -32,7 +32,7 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"),
+    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"),
             os.path.join(CSRC, "yy_bitboard.h"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
@@ -81,6 +81,10 @@ _SIGS = {
     "yy_nn_head_finish_bf16": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     "yy_nn_tower_f32": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_bf16x3": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_tower_f16x3": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_tower_heads_f16x3": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_head_finish_f32": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "yy_compact_rows": [_vp, C.c_int, _vp, _vp, _vp],
     "yy_version": [],
 }
 

@@ -457,7 +457,8 @@ struct GameState {
     uint8_t active, err, root_w_is_py;
     uint8_t leaf_kind;
     int8_t leaf_player;
-    uint8_t leaf_terminal, pad0;
+    uint8_t leaf_terminal;
+    uint8_t err_ever;       // sticky: set with err, survives yy_mcts_begin, cleared only by yy_mcts_status
     uint64_t leaf_board[2 * YY_MAX_NW];
     uint64_t leaf_mask[YY_MAX_NW];
     uint64_t ctr[6];        // evals, levels, children scanned, children created, terminal revisits, nodes
@@ -613,7 +614,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         const int k = node_k(hy), first = rfl((int)hdr.x);
         if (node_flags(hy) & NF_TERMINAL) { kind = K_TERMINAL; break; }            // mcts.py:360, 365
         if (k == 0) { kind = (node == 0) ? K_ROOTPASS : K_REEXPAND; break; }      // mcts.py:93-95
-        if (depth >= (int)d.path_cap) { kind = K_NONE; if (lane == 0) st->err = 1; break; }
+        if (depth >= (int)d.path_cap) { kind = K_NONE; if (lane == 0) st->err = st->err_ever = 1; break; }
         // ---- Node.select_child (mcts.py:97-145), float32 order of SURVEY 8a/a12
         // sum of child visits (mcts.py:112).  Copied boards: every visit of an expanded node after its
         // first descends into exactly one child, so the sum is N(node)-1 (root: completed simulations) and
@@ -652,7 +653,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             best = (mx == 0u || mi == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)mi;
         }
         if (mx == 0u) best = 0x7FFFFFFF;
-        if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = 1; break; }  // NaN priors
+        if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = st->err_ever = 1; break; }  // NaN priors
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)bw, best & 63);
         s_carry = (int)__builtin_amdgcn_readlane((int)bn, best & 63) - 1;
         if (lane == 0) path[depth] = first + best;
@@ -751,12 +752,16 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         v_is_py = true;
     } else {
         v = (kind == K_ROOTINIT) ? 0.0f : rflf(value[g]);
+        if (v != v) {   // a NaN from the evaluator must not enter the statistics: the game stops searching, the error is sticky
+            if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
+            return;
+        }
         const int A = d.geo.A;
         const int lplayer = rfl((int)st->leaf_player);
         const bool term = rfl((int)st->leaf_terminal) != 0;
         int n_nodes = rfl(st->n_nodes), n_edges = rfl(st->n_edges);
         if (kind == K_EXPAND) {
-            if (n_nodes >= (int)d.node_cap) { if (lane == 0) { st->err = 1; st->leaf_kind = K_NONE; } return; }
+            if (n_nodes >= (int)d.node_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
             node = n_nodes++;
             if (lane == 0) {
                 uint4 *pe = edges + path[depth - 1];
@@ -779,7 +784,7 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                 nodes[node] = make_uint4(0u, node_pack(0, NF_TERMINAL, lplayer), __float_as_uint(st->leaf_tv), 0u);
         } else {                                                                    // mcts.py:71-89
             const int k = bb_popc(mask);
-            if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = 1; st->leaf_kind = K_NONE; } return; }
+            if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
             const float keep = (float)(1.0 - d.eps);
             // a game whose noise row is all zero over its legal moves drew no noise (a Dirichlet draw
             // sums to 1): it keeps the raw priors, like add_exploration_noise=False (mcts.py:298)
@@ -938,9 +943,10 @@ template <int NW> __global__ void __launch_bounds__(64) k_get_boards(MctsDev d, 
 __global__ void k_status(MctsDev d, uint64_t *out /*[8]: 6 counters, overflow games, 0*/) {
     uint64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < d.G; g += gridDim.x * blockDim.x) {
-        const GameState *st = d.state + g;
+        GameState *st = d.state + g;
         for (int i = 0; i < 6; i++) acc[i] += st->ctr[i];
-        acc[6] += st->err ? 1 : 0;
+        acc[6] += (st->err || st->err_ever) ? 1 : 0;   // a failure in ANY search since the last status call
+        st->err_ever = 0;
     }
     for (int i = 0; i < 7; i++)
         if (acc[i]) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
@@ -1116,7 +1122,7 @@ extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counter
         counters[6] = counters[7] = 0;
     }
     if (n_overflow) *n_overflow = (int32_t)h[6];
-    if (h[6]) return set_err(YY_E_ARENA, "tree arena overflow in at least one game%s%s");
+    if (h[6]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
     return YY_OK;
 }
 
@@ -1227,6 +1233,77 @@ __global__ void __launch_bounds__(64) k_head_finish(const unsigned short *__rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) value[g] = tanhf(acc + b2[0]);
+}
+
+// float32 head finish (evaluator modes "f16x3" / float32 towers): logits f32 [Gd, A] and value_fc1 outputs f32 [Gd, H]
+// (bias added, no ReLU yet) of DENSE row i -> policy[g] = softmax(logits[i]), value[g] = tanh(relu(hidden[i]) . w2 + b2)
+// with g = rows ? rows[i] : i; blocks i >= *n_rows exit (the rows a compacted launch did not evaluate).
+__global__ void __launch_bounds__(64) k_head_finish_f32(const float *__restrict__ logits, const float *__restrict__ hidden,
+                                                        int A, int H, const float *__restrict__ w2,
+                                                        const float *__restrict__ b2, const int32_t *__restrict__ rows,
+                                                        const int32_t *__restrict__ n_rows, float *__restrict__ policy,
+                                                        float *__restrict__ value) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (n_rows && i >= *n_rows) return;
+    const int g = rows ? rows[i] : i;
+    const float *row = logits + (size_t)i * A;
+    float mx = -INFINITY;
+    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, row[a]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int a = lane; a < A; a += 64) sum += expf(row[a] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int a = lane; a < A; a += 64) policy[(size_t)g * A + a] = expf(row[a] - mx) / sum;
+    const float *hr = hidden + (size_t)i * H;
+    float acc = 0.0f;
+    for (int j = lane; j < H; j += 64) acc += fmaxf(hr[j], 0.0f) * w2[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) value[g] = tanhf(acc + b2[0]);
+}
+
+extern "C" int yy_nn_head_finish_f32(const float *logits, const float *hidden, int G, int A, int H, const float *w2,
+                                     const float *b2, const int32_t *rows, const int32_t *n_rows, float *policy, float *value,
+                                     yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (!logits || !hidden || !w2 || !b2 || !policy || !value || G < 0 || A <= 0 || H <= 0 || (rows && !n_rows))
+        return set_err(YY_E_INVALID, "bad argument%s%s");
+    k_head_finish_f32<<<dim3(G), dim3(64), 0, (hipStream_t)s>>>(logits, hidden, A, H, w2, b2, rows, n_rows, policy, value);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+// Leaf-batch compaction: rows[0 .. *n) = the indices g with flags[g] != 0, ascending; one 1024-thread workgroup.
+__global__ void __launch_bounds__(1024) k_compact_rows(const uint8_t *__restrict__ flags, int G, int32_t *__restrict__ rows,
+                                                       int32_t *__restrict__ n) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (G + 1023) / 1024, lo = min(t * per, G), hi = min(lo + per, G);
+    int cnt = 0;
+    for (int g = lo; g < hi; g++) cnt += flags[g] != 0;
+    int incl = cnt;                                             // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    int pos = base + incl - cnt;
+    for (int g = lo; g < hi; g++)
+        if (flags[g] != 0) rows[pos++] = g;
+    if (t == 1023) *n = base + incl;
+}
+
+extern "C" int yy_compact_rows(const uint8_t *flags, int G, int32_t *rows, int32_t *n, yy_stream_t s) {
+    if (!flags || !rows || !n || G < 0) return set_err(YY_E_INVALID, "bad argument%s%s");
+    k_compact_rows<<<dim3(1), dim3(1024), 0, (hipStream_t)s>>>(flags, G, rows, n);
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
 }
 
 extern "C" int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2, float *policy,

@@ -176,6 +176,75 @@ def tower_forward_x3(planes, weights, bias, n_layers):
     return out.permute(0, 3, 1, 2)
 
 
+def tower_forward_h3(planes, weights, bias, n_layers):
+    """Stem + residual tower at float32 accuracy on the f16 MFMA (split-f16, csrc/yy_tower_h3.hip / yy_tower_h3q.hip).
+    planes f32 [G,5,R,R] (R = 6, 8, 12) -> f32 activations as a channels-last tensor [G,128,R,R]."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
+    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "split-f16 tower weights")
+    _need(bias, torch.float32, (n_layers, 128), "tower bias")
+    out = torch.empty((G, R, Cc, 128), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_f16x3(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, _stream()))
+    return out.permute(0, 3, 1, 2)
+
+
+def tower_heads_forward_h3(planes, weights, bias, n_layers, rows=None, n_rows=None, out=None):
+    """Split-f16 tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] -> f32 [G,2,32*R*R] = (policy features, value
+    features) in the reference's flatten order.  rows int32 [G] / n_rows int32 [1] (device): evaluate planes[rows[i]] for
+    i < n_rows into output row i (the other output rows are left untouched)."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
+    _need(weights, torch.int16, (9 + 36 * (n_layers - 1) + 2, 8192), "split-f16 tower+heads weights")
+    _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
+    if rows is not None:
+        _need(rows, torch.int32, (G,), "rows")
+        _need(n_rows, torch.int32, (1,), "n_rows")
+    if out is None:
+        out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
+    _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_heads_f16x3(_p(planes), _p(weights), _p(bias), _p(out), _p(rows), _p(n_rows), G, R, Cc, 128,
+                                            n_layers, _stream()))
+    return out
+
+
+def head_finish_f32(logits, hidden, w2, b2, rows=None, n_rows=None, policy=None, value=None):
+    """softmax(logits f32 [G,A]) and tanh(relu(hidden f32 [G,H]) @ w2 + b2) in one HIP pass (csrc k_head_finish_f32);
+    with rows / n_rows the result of dense row i lands in row rows[i] of (policy, value) for i < n_rows."""
+    G, A = logits.shape
+    _need(logits, torch.float32, name="logits")
+    _need(hidden, torch.float32, (G, hidden.shape[1]), "hidden")
+    _need(w2, torch.float32, (hidden.shape[1],), "w2")
+    _need(b2, torch.float32, (1,), "b2")
+    if rows is not None:
+        _need(rows, torch.int32, (G,), "rows")
+        _need(n_rows, torch.int32, (1,), "n_rows")
+    if policy is None:
+        policy = torch.zeros((G, A), dtype=torch.float32, device=logits.device)
+        value = torch.zeros(G, dtype=torch.float32, device=logits.device)
+    _need(policy, torch.float32, (G, A), "policy")
+    _need(value, torch.float32, (G,), "value")
+    with torch.cuda.device(logits.device):
+        check(lib().yy_nn_head_finish_f32(_p(logits), _p(hidden), G, A, hidden.shape[1], _p(w2), _p(b2), _p(rows), _p(n_rows),
+                                          _p(policy), _p(value), _stream()))
+    return policy, value
+
+
+def compact_rows(flags, rows=None, n=None):
+    """uint8 [G] flags -> (rows int32 [G], n int32 [1]): rows[:n] = ascending indices of the non-zero flags."""
+    G = flags.shape[0]
+    _need(flags, torch.uint8, (G,), "flags")
+    if rows is None:
+        rows = torch.zeros(G, dtype=torch.int32, device=flags.device)
+        n = torch.zeros(1, dtype=torch.int32, device=flags.device)
+    _need(rows, torch.int32, (G,), "rows")
+    _need(n, torch.int32, (1,), "n")
+    with torch.cuda.device(flags.device):
+        check(lib().yy_compact_rows(_p(flags), G, _p(rows), _p(n), _stream()))
+    return rows, n
+
+
 def tower_heads_forward(planes, weights, bias, n_layers):
     """Tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] (R = 8 or 12) ->
     bf16 [G,2,32*R*R] = (policy features, value features) in the reference's flatten order."""

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+H3_BOARDS = ((8, 8),)      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
 INPUT_PLANES = 5
@@ -204,6 +205,61 @@ def pack_tower_x3(net):
     return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
 
 
+LO_SCALE = 2048.0      # csrc/yy_tower_h3.hip: lo = f16((x - hi) * 2^11)
+
+
+def split_f16(t):
+    """x -> (hi, lo) float16 with x == hi + lo * 2^-11 to 22 significant bits (csrc/yy_tower_h3.hip)."""
+    t = t.float()
+    hi = t.to(torch.float16)
+    if not bool(torch.isfinite(hi).all()):
+        raise ValueError("split-f16 evaluator: a folded weight exceeds the float16 range (|w| > 65504)")
+    lo = ((t - hi.float()) * LO_SCALE).to(torch.float16)
+    return hi, lo
+
+
+def pack_tower_h3(net):
+    """Split-f16 packing for csrc/yy_tower_h3.hip (evaluator mode "f16x3"): every folded float32 weight w becomes
+    hi = f16(w), lo = f16((w - hi) * 2^11); chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] f16 with
+    cout = nt*32 + c and cin = quarter*32 + ks*16 + h*8 + j (part 0 = hi, 1 = lo); the stem has one chunk per tap (5 planes
+    padded to 16 channels, ks = 0 only), every other layer 36 (tap-major, then quarter).
+    Returns int16 [n_chunks, 8192] (f16 bits), float32 bias [n_layers, 128]."""
+    convs = [(net.conv1, net.bn1)]
+    for blk in net.res_blocks:
+        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    chunks, biases = [], []
+    for li, (conv, bn) in enumerate(convs):
+        w, b = fold_batchnorm(conv, bn)
+        w = w.float().cpu()
+        wp = torch.zeros((128, 128, 3, 3))
+        wp[:, :w.shape[1]] = w
+        hi, lo = split_f16(wp)
+        for tap in range(9):
+            parts = []
+            for t in (hi, lo):
+                t = t[:, :, tap // 3, tap % 3].reshape(4, 32, 4, 2, 2, 8)         # nt, c, quarter, ks, h, j
+                parts.append(t.permute(2, 3, 0, 4, 1, 5))                          # quarter, ks, nt, h, c, j
+            both = torch.stack(parts, dim=2).contiguous()                          # quarter, ks, part, nt, h, c, j
+            for quarter in range(1 if li == 0 else 4):
+                chunks.append(both[quarter].reshape(-1))
+        biases.append(b.float().cpu())
+    return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
+
+
+def pack_heads_h3(net):
+    """The two 1x1 head convolutions for csrc/yy_tower_h3.hip / yy_tower_h3q.hip: two chunks [ks 4][part 2][nt 2][h 2][c 32][j 8]
+    f16 (nt 0 = policy channels, nt 1 = value channels, cin = chunk*64 + ks*16 + h*8 + j) and one bias row
+    [policy 32 | value 32 | zeros]."""
+    wp, bp = fold_batchnorm(net.policy_conv, net.policy_bn)      # [32,128,1,1]
+    wv, bv = fold_batchnorm(net.value_conv, net.value_bn)
+    w = torch.cat([wp, wv]).float().cpu().reshape(2, 32, 2, 4, 2, 8)            # nt, c, chunk, ks, h, j
+    parts = [t.permute(2, 3, 0, 4, 1, 5) for t in split_f16(w)]                  # chunk, ks, nt, h, c, j
+    both = torch.stack(parts, dim=2).contiguous()                                # chunk, ks, part, nt, h, c, j
+    bias = torch.zeros(1, 128)
+    bias[0, :32], bias[0, 32:64] = bp.float().cpu(), bv.float().cpu()
+    return both.reshape(2, -1).view(torch.int16).contiguous(), bias
+
+
 def pack_heads(net):
     """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
     [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
@@ -242,6 +298,21 @@ class BatchedEvaluator:
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
                       and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
+        if mode == "f16x3":
+            if tuple(net.board_size) not in H3_BOARDS or net.conv1.out_channels != 128 or len(net.res_blocks) > 10 \
+                    or net.policy_conv.out_channels != 32:
+                raise ValueError("f16x3 needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks")
+            (wq, bq), (hw, hb) = pack_tower_h3(net), pack_heads_h3(net)
+            self.h3_w = torch.cat([wq, hw]).contiguous().to(self.device)
+            self.h3_b = torch.cat([bq, hb]).contiguous().to(self.device)
+            self.h3_layers = 1 + 2 * len(net.res_blocks)
+            f32 = lambda t: t.detach().float().contiguous().to(self.device)
+            self.pfc_wt, self.pfc_b = f32(net.policy_fc.weight.t()), f32(net.policy_fc.bias)
+            self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
+            self.fc2_w, self.fc2_b = f32(net.value_fc2.weight.reshape(-1)), f32(net.value_fc2.bias.reshape(1))
+            self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
+            self.tower = False
+            return
         if mode in ("fp32t", "bf16x3"):
             if tuple(net.board_size) != (8, 8) or net.conv1.out_channels != 128 or len(net.res_blocks) > 11:
                 raise ValueError(mode + " needs 8x8 boards, 128 channels, at most 11 residual blocks")
@@ -315,7 +386,20 @@ class BatchedEvaluator:
         return engine.bias_act_(y, b, residual, relu=True)
 
     @torch.no_grad()
-    def __call__(self, planes):
+    def __call__(self, planes, needs_eval=None):
+        """needs_eval (uint8 [G], modes with `supports_compaction` only): evaluate just the flagged rows -- the tower launch
+        gathers them, the other rows of the returned (policy, value) hold zeros and must not be read."""
+        if self.mode == "f16x3":
+            from . import engine
+            rows = n = None
+            if needs_eval is not None:
+                rows, n = engine.compact_rows(needs_eval)
+            feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, rows, n)   # [G, 2, 32*cells] f32
+            logits = torch.addmm(self.pfc_b, feats[:, 0], self.pfc_wt)                                    # [G, A]
+            hidden = torch.addmm(self.vfc1_b, feats[:, 1], self.vfc1_wt)                                  # [G, 256]
+            return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n)
+        if needs_eval is not None:
+            raise ValueError(f"evaluator mode {self.mode} does not take needs_eval")
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
         if self.mode in ("fp32t", "bf16x3"):

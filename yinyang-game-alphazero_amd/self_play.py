@@ -54,12 +54,17 @@ class LockstepSearch:
         else:
             self.graphs[self.ctx.G] = g
 
-    def _evaluate(self, rows):
-        """Evaluator on the first `rows` leaf rows (all searching games must sit there); returns full-height buffers."""
+    def _evaluate(self, rows, compact=False):
+        """Evaluator on the first `rows` leaf rows (all searching games must sit there); returns full-height buffers.
+        compact: pass the step's needs_eval flags to an evaluator that can skip the rows whose leaf needs no evaluation
+        (terminal revisits, mcts.py:365-366; finished or idle slots)."""
         ctx = self.ctx
+        kw = {}
+        if compact and getattr(self.evaluator, "supports_compaction", False):
+            kw["needs_eval"] = ctx.needs_eval if rows >= ctx.G else ctx.needs_eval[:rows]
         if rows >= ctx.G:
-            return self.evaluator(ctx.planes)
-        policy, value = self.evaluator(ctx.planes[:rows])
+            return self.evaluator(ctx.planes, **kw)
+        policy, value = self.evaluator(ctx.planes[:rows], **kw)
         if self._policy is None:
             self._policy = torch.zeros((ctx.G, policy.shape[1]), dtype=torch.float32, device=ctx.device)
             self._value = torch.zeros(ctx.G, dtype=torch.float32, device=ctx.device)
@@ -68,7 +73,7 @@ class LockstepSearch:
         return self._policy, self._value
 
     def _sim_step(self, rows):
-        policy, value = self._evaluate(rows)
+        policy, value = self._evaluate(rows, compact=True)
         if self.timer is not None:
             self.timer.start()
         self.ctx.step(policy, value)
@@ -104,7 +109,7 @@ class LockstepSearch:
             else:
                 self._sim_step(rows)
             done += 1
-        policy, value = self._evaluate(rows)                   # last simulation: no further select
+        policy, value = self._evaluate(rows, compact=True)     # last simulation: no further select
         ctx.expand_backup(policy, value)
 
 
