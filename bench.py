@@ -5,11 +5,18 @@ node-expansions/s at 800 sims on 8x8).
     python bench.py --gpus N --steps K --warmup W          (N=1: plain python; N>1: torchrun)
 
 A "step" = one lockstep MOVE of all G concurrent games = 1 root evaluation + `sims` simulations,
-each simulation being one fused HIP tree kernel + one batched CNN forward over G leaves, then the
-move itself (root policy, sampling, rules step, game-ended test, slot refill).  Workload = config[1]
-of BASELINE.json: 8x8, 800 sims, 4096 concurrent games per GPU, frozen random-init 128x10 net
-(torch.manual_seed(0)); games start at staggered plies from seeded random legal play so the batch
-is in the steady state of continuous self-play.  value = positions/s over all ranks.
+each simulation being one fused HIP tree kernel + one batched CNN forward over the leaves that need
+one, then the move itself (root policy, sampling, rules step, game-ended test, slot refill).
+Workload = config[1] of BASELINE.json: 8x8, 800 sims, 4096 concurrent games per GPU, frozen random-init
+128x10 net (torch.manual_seed(0)); games start at staggered plies from seeded random legal play so the
+batch is in the steady state of continuous self-play.  value = positions/s over all ranks.
+
+The headline leg runs the evaluator at the REFERENCE's precision: `--nn f16x3` = the split-f16 tower
+(csrc/yy_tower_h3.hip: float32-accurate, identical visit counts to the reference's CPU float32 search on all
+64 golden roots -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 two more
+legs are timed in the same run and reported as extra keys of the same JSON line: `secondary` = the bf16
+tower (reduced precision: NOT the headline) and `oversubscribed` = the headline evaluator with enough
+concurrent games that the compacted leaf batch fills whole workgroup rounds.
 """
 import argparse
 import ctypes
@@ -26,8 +33,11 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 MFMA ~2.5 PFLOP/s dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 / f16 MFMA ~2.5 PFLOP/s dense
 MFMA_F32_PEAK_TFLOPS = 157.3    # same guide: f32-input MFMA = the f32 vector rate
+NN_MODES = ["f16x3", "bf16", "fp16", "fp32", "fp32t", "bf16x3"]
+FP32_GRADE = {"f16x3": "float32-accurate split-f16 MFMA (hi + lo*2^-11 float16 pairs, f32 accumulate)",
+              "fp32t": "exact float32 MFMA", "fp32": "float32 (PyTorch/MIOpen)"}
 
 
 def parse():
@@ -41,12 +51,22 @@ def parse():
     ap.add_argument("--cols", type=int, default=8)
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--blocks", type=int, default=10)
-    ap.add_argument("--nn", default="bf16", choices=["bf16", "fp16", "fp32", "fp32t", "bf16x3"])
+    ap.add_argument("--nn", default="f16x3", choices=NN_MODES,
+                    help="evaluator of the headline leg; f16x3 = float32-accurate (the reference evaluates in float32)")
+    ap.add_argument("--secondary-nn", default="bf16", choices=NN_MODES + ["none"],
+                    help="N=1 only: a second, shorter leg with this evaluator, reported under `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--oversubscribe", type=int, default=-1,
+                    help="N=1 only: a third leg with this many concurrent games (compacted leaf batch ~ whole workgroup "
+                         "rounds); -1 = 4320 for the default workload, 0 = skip")
+    ap.add_argument("--oversubscribe-steps", type=int, default=3)
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline sample: half per board semantics")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU baseline processes (0 = one per host core, at most 16)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg (no GPU needed) and print it")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow with several ranks sharing ONE GPU (RCCL needs a "
                          "device per rank); the exchange then goes through host memory")
@@ -91,7 +111,7 @@ def stagger_start(eng, seed):
 
 class HipEventTimer:
     """HIP events (hipEventRecord on the stream the kernel is launched on, via the HIP runtime itself,
-    not torch.cuda.Event) around every launch of the fused tree kernel."""
+    not torch.cuda.Event) around every launch of a kernel."""
 
     def __init__(self, n):
         self.hip = ctypes.CDLL("libamdhip64.so")
@@ -126,10 +146,46 @@ class HipEventTimer:
         return tot / max(self.i, 1), self.i
 
 
+def tower_launcher(eng):
+    """(callable launching the evaluator's dominant kernel ALONE on the live leaf batch, kernel name, algorithmic FLOPs per
+    launch, MFMA peak it is priced against) or None when the evaluator has no hand-written tower."""
+    from yinyang_game_alphazero_amd import engine as E
+    ev, G = eng.evaluator, eng.G
+    cells, blocks = eng.R * eng.C, len(ev.net.res_blocks)
+    body = 2 * blocks * (2 * 9 * 128 * 128 * cells)
+    heads = 2 * 128 * 64 * cells
+    mode = getattr(ev, "mode", "")
+    planes = eng.ctx.planes
+    if mode == "f16x3":
+        form = {8: "k_tower_h3 (two boards per workgroup)", 6: "k_tower_h3q<6,4>", 12: "k_tower_h3q<12,1>"}[eng.R]
+        return (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers),
+                form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
+                       "peak = f16 MFMA dense peak / 3",
+                (2 * 9 * 16 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
+    if mode == "bf16x3":
+        return (lambda: E.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers),
+                "k_tower_x3: stem + residual tower, split-bf16 (3 bf16 MFMAs per product term); peak = bf16 MFMA peak / 3",
+                (2 * 9 * 16 * 128 * cells + body) * G, MFMA_BF16_PEAK_TFLOPS / 3)
+    if mode == "fp32t":
+        return (lambda: E.tower_forward_f32(planes, ev.f32_w, ev.f32_b, ev.f32_layers),
+                "k_tower_f32: stem + residual tower, exact f32 MFMA 32x32x2", (2 * 9 * 8 * 128 * cells + body) * G,
+                MFMA_F32_PEAK_TFLOPS)
+    if getattr(ev, "tower", False):
+        name = {6: "k_towerq<6,8>", 8: "k_tower" if G > 512 else "k_towerq<8,%d>" % (1 if G <= 256 else 2),
+                12: "k_towerq<12,2>"}.get(eng.R, "k_tower")
+        if getattr(ev, "fused_heads", False):
+            return (lambda: E.tower_heads_forward(planes, ev.towerh_w, ev.towerh_b, ev.tower_layers),
+                    name + ": stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident",
+                    (2 * 9 * 16 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS)
+        return (lambda: E.tower_forward(planes, ev.tower_w, ev.tower_b, ev.tower_layers),
+                name + ": stem + residual tower, bf16 MFMA", (2 * 9 * 16 * 128 * cells + body) * G, MFMA_BF16_PEAK_TFLOPS)
+    return None
+
+
 def roofline_pass(eng):
     """One more move of the SAME workload, launched eagerly (same kernels as the graph replays) with HIP
     events around every fused tree-kernel launch; returns (mean kernel ms, launches, device counters of
-    exactly those launches, mean evaluator-forward ms)."""
+    exactly those launches, mean evaluator-forward ms, move ms, mean dominant-kernel ms or None)."""
     eng.search.use_graph, eng.search.graph = False, None
     eng.ctx.reset_counters()
     timer = HipEventTimer(eng.sims)
@@ -143,7 +199,7 @@ def roofline_pass(eng):
     k_ms, n = timer.mean_ms()
     counters = eng.ctx.status()
     move_ms = t0.elapsed_time(t1)
-    # evaluator forward alone, same batch
+    # evaluator forward alone (every row), same batch
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     reps = 20
@@ -152,27 +208,13 @@ def roofline_pass(eng):
         eng.evaluator(eng.ctx.planes)
     e1.record()
     torch.cuda.synchronize()
-    # the tower kernel alone (HIP events on its launch stream), when the evaluator uses it
     tower_ms = None
-    ev = eng.evaluator
-    if getattr(ev, "mode", "") in ("fp32t", "bf16x3"):
-        from yinyang_game_alphazero_amd import engine as E
-        tower = E.tower_forward_f32 if ev.mode == "fp32t" else E.tower_forward_x3
-        tt = HipEventTimer(5)
-        for _ in range(5):
-            tt.start()
-            tower(eng.ctx.planes, ev.f32_w, ev.f32_b, ev.f32_layers)
-            tt.stop()
-        tower_ms, _ = tt.mean_ms()
-    if getattr(ev, "tower", False):
-        from yinyang_game_alphazero_amd import engine as E
+    tl = tower_launcher(eng)
+    if tl is not None:      # the dominant kernel alone: HIP events on its launch stream
         tt = HipEventTimer(reps)
         for _ in range(reps):
             tt.start()
-            if getattr(ev, "fused_heads", False):
-                E.tower_heads_forward(eng.ctx.planes, ev.towerh_w, ev.towerh_b, ev.tower_layers)
-            else:
-                E.tower_forward(eng.ctx.planes, ev.tower_w, ev.tower_b, ev.tower_layers)
+            tl[0]()
             tt.stop()
         tower_ms, _ = tt.mean_ms()
     return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms
@@ -193,45 +235,178 @@ def algorithmic_bytes(counters, G, A, n_steps, nw):
                                  bytes_per_expansion=total / ev)
 
 
-def cpu_baseline(args):
-    """The CPU restatement (oracle/yy_oracle.c: same float32 PUCT, copied semantics) driving the same
-    network under PyTorch CPU, batch 1 like the reference (self_play.py:54-59), timed on this host for
-    a bounded sample: repeated `sims`-simulation searches from the empty board until ~cpu_seconds."""
+# ------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(job):
+    """One host process = one core: the CPU restatement's tree (oracle/yy_oracle.c: same float32 PUCT) driving the same
+    network under PyTorch CPU at batch 1 like the reference (self_play.py:54-59), ONE `sims`-simulation search from the
+    empty board with root noise from the per-game seed 1000 + game index; evaluations are counted until the deadline, after
+    which the callback stops calling the network so the process ends quickly."""
+    idx, rows, cols, channels, blocks, sims, copied, seconds = job
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from yinyang_game_alphazero_amd.game import YinYangGame
     from yinyang_game_alphazero_amd.network import YinYangNeuralNetwork
+    torch.set_num_threads(1)
     torch.manual_seed(0)
-    net = YinYangNeuralNetwork(YinYangGame(args.rows, args.cols), args.channels, args.blocks).eval()
-    # the GPU box gives one GPU's share of the host: 16 cores (intra-op threads beyond that only add
-    # contention for batch-1 convolutions)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    cores = torch.get_num_threads()
-    enc = O.encode_planes
+    net = YinYangNeuralNetwork(YinYangGame(rows, cols), channels, blocks).eval()
+    A = rows * cols
+    rng = np.random.RandomState(1000 + idx)
+    noise = rng.dirichlet([0.3] * A)            # every cell is legal on the empty board
+    state = dict(n=0, t0=None, dt=0.0, last=None)
 
     def predict(board):
-        x = torch.from_numpy(enc(np.ascontiguousarray(board)[None]))
+        now = time.perf_counter()
+        if state["t0"] is None:
+            state["t0"] = now
+        if now - state["t0"] >= seconds and state["last"] is not None:
+            return state["last"]                # past the deadline: not counted, not evaluated
+        x = torch.from_numpy(O.encode_planes(np.ascontiguousarray(board)[None]))
         with torch.no_grad():
             logits, v = net(x)
             p = torch.softmax(logits, 1)
-        return p[0].numpy(), float(v[0, 0])
+        state["last"] = (p[0].numpy(), float(v[0, 0]))
+        state["n"] += 1
+        state["dt"] = time.perf_counter() - state["t0"]
+        return state["last"]
 
-    sims = min(args.sims, 200)
+    O.search_callback(np.zeros((rows, cols), np.int8), 1, sims, copied, predict, noise=noise)
+    return state["n"], state["dt"]
+
+
+def cpu_baseline(args):
+    import multiprocessing as mp
+    cores = args.cpu_workers or min(16, os.cpu_count() or 1)     # a 1-GPU box's share of the host is 16 cores
+    half = args.cpu_seconds / 2
+    out = {}
+    ctx = mp.get_context("spawn")                                # the parent holds a GPU context: never fork it
+    with ctx.Pool(cores) as pool:
+        for name, copied in (("copied", 1), ("aliased", 0)):
+            jobs = [(i, args.rows, args.cols, args.channels, args.blocks, args.sims, copied, half) for i in range(cores)]
+            res = pool.map(_cpu_worker, jobs, chunksize=1)
+            out[name] = sum(n / max(dt, 1e-9) for n, dt in res)
+    v = out["copied"]
+    return {"value": v, "unit": "expansions/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes (one per host core, 1 torch thread each), each the first {half:.0f} s of one "
+                      f"{args.sims}-simulation search from the empty {args.rows}x{args.cols} board (per-game seed 1000+i, root "
+                      f"noise), batch-1 fp32 {args.channels}x{args.blocks} net on torch CPU, oracle/yy_oracle.c tree; value = "
+                      f"copied boards, aliased (literal reference semantics) alongside",
+            "aliased_expansions_per_s": out["aliased"],
+            "positions_per_s": v / (args.sims + 1),
+            "python_reference_anchor": "BASELINE.md section 2: 103 (copied) / 117 (aliased) simulations/s per 8-core process"}
+
+
+# ------------------------------------------------------------------------------------------- one timed leg
+def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofline):
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, gather_examples
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(args.rows, args.cols)
+    net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
+    evaluator = pkg.BatchedEvaluator(net, nn)
+    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games,
+                         board_semantics=args.semantics, reference_quirks=args.quirks,
+                         use_graph=not args.no_graph, seed=1000, device=dev,
+                         first_game_index=rank, game_index_stride=world)
+    stagger_start(eng, 4242 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        eng.play_move()
+    eng.collect()
+    eng.ctx.reset_counters()
+    barrier()
     t0 = time.perf_counter()
-    evals = 0
-    n = 0
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        r = O.search_callback(np.zeros((args.rows, args.cols), np.int8), 1, sims, 1, predict)
-        evals += r.n_evals + 1
-        n += 1
+    positions = 0
+    for _ in range(steps):
+        positions += eng.play_move()
+    barrier()
     dt = time.perf_counter() - t0
-    return {"value": evals / dt, "unit": "expansions/s", "cores": cores, "kind": "port",
-            "sample": f"{n} searches x {sims} sims from the empty {args.rows}x{args.cols} board, batch-1 fp32 "
-                      f"{args.channels}x{args.blocks} net on torch CPU ({cores} threads), oracle/yy_oracle.c tree",
-            "positions_per_s": evals / dt / (args.sims + 1)}
+    counters = eng.ctx.status()
+    ex = eng.collect()
+    # the single exchange of the path: all-gather the examples produced in the timed region
+    tg0 = time.perf_counter()
+    ex_all = gather_examples(ex if cdev == dev else {k: v.to(cdev) for k, v in ex.items()})
+    torch.cuda.synchronize()
+    gather_s = time.perf_counter() - tg0
+    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=cdev)
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt = float(mx[2])
+    leg = dict(nn=nn, games=games, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), gather_s=gather_s,
+               examples=int(ex_all["states"].shape[0]), sims_total=steps * args.sims * games * world,
+               eval_fraction=counters["evals"] / max(steps * args.sims * games, 1))
+    if with_roofline and rank == 0:
+        leg["roofline"] = make_roofline(args, eng, games)
+    eng.close()
+    del eng, evaluator, net
+    torch.cuda.empty_cache()
+    return leg
+
+
+def pmc_traffic(name, key):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (collected OFFLINE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes) when its recorded configuration equals this run's; else (None, why)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"no offline PMC summary profiles/{name}"
+    rec = json.load(open(path))
+    if rec.get("config") != key:
+        return None, f"profiles/{name} was collected for {rec.get('config')}, not for this configuration"
+    return rec["per_launch_bytes"]["traffic_corrected"], f"profiles/{name} (offline rocprofv3 --pmc passes, not measured in this run)"
+
+
+def make_roofline(args, eng, games):
+    k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms = roofline_pass(eng)
+    A = args.rows * args.cols
+    nw = (A + 63) // 64
+    bytes_per_launch, shape = algorithmic_bytes(kc, games, A, n_launch, nw)
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    key = dict(games=games, rows=args.rows, cols=args.cols, sims=args.sims, channels=args.channels, blocks=args.blocks)
+    traffic, src = pmc_traffic("r02_k_mcts_pmc.json", key)
+    roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                 "traffic_source": src, "avg_launch_ms": k_ms, "launches_timed": n_launch,
+                 "algorithmic_bytes_per_launch": bytes_per_launch, **shape}
+    out = {"roofline": roof_tree}
+    tl = tower_launcher(eng)
+    if tl is not None and tower_ms is not None:
+        _, name, flops, peak = tl
+        ach = flops / (tower_ms * 1e-3) / 1e12
+        mode = getattr(eng.evaluator, "mode", "")
+        traffic, src = pmc_traffic(f"r02_k_tower_{mode}_hbm_pmc.json", key)
+        out = {"roofline": {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                            "frac": ach / peak, "traffic": traffic, "traffic_source": src, "avg_launch_ms": tower_ms,
+                            "algorithmic_flops_per_launch": flops,
+                            "timed": "20 launches on every row of the live leaf batch, hipEventRecord on the launch stream"},
+               "roofline_tree_kernel": roof_tree}
+    Cc = args.channels
+    flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
+                  + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
+    out.update(nn_forward_ms=nn_ms, nn_tflops=flops_leaf * games / (nn_ms * 1e-3) / 1e12, tree_kernel_ms=k_ms,
+               tree_kernel_only_expansions_per_s=kc["evals"] / max(n_launch, 1) / (k_ms * 1e-3), eager_move_ms=eager_move_ms)
+    return out
+
+
+def leg_summary(leg, note):
+    return {"nn": leg["nn"], "games_per_gpu": leg["games"], "steps": leg["steps"], "value": leg["positions"] / leg["dt"],
+            "unit": "positions/s", "expansions_per_s": leg["evals"] / leg["dt"], "simulations_per_s": leg["sims_total"] / leg["dt"],
+            "ms_per_step": leg["dt"] / leg["steps"] * 1e3, "eval_fraction": leg["eval_fraction"], "note": note}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -258,128 +433,50 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    import yinyang_game_alphazero_amd as pkg
-    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, gather_examples
-
     dev = torch.device("cuda", local)
-    torch.manual_seed(0)
-    game = pkg.YinYangGame(args.rows, args.cols)
-    net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
-    evaluator = pkg.BatchedEvaluator(net, args.nn)
-    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=args.games,
-                         board_semantics=args.semantics, reference_quirks=args.quirks,
-                         use_graph=not args.no_graph, seed=1000 + rank, device=dev,
-                         first_game_index=rank, game_index_stride=world)
-    stagger_start(eng, 4242 + rank)
-
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collectives run
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.play_move()
-    eng.collect()
-    eng.ctx.reset_counters()
-    barrier()
-    t0 = time.perf_counter()
-    positions = 0
-    for _ in range(args.steps):
-        positions += eng.play_move()
-    barrier()
-    dt = time.perf_counter() - t0
-    counters = eng.ctx.status()
-    ex = eng.collect()
-    # the single exchange of the path: all-gather the examples produced in the timed region
-    tg0 = time.perf_counter()
-    ex_all = gather_examples(ex if cdev == dev else {k: v.to(cdev) for k, v in ex.items()})
-    torch.cuda.synchronize()
-    gather_s = time.perf_counter() - tg0
-    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=cdev)
-    if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dt = float(mx[2])
-    positions_all, evals_all = float(tot[0]), float(tot[1])
-
-    roof = cpub = None
+    main_leg = run_leg(args, args.nn, args.games, args.steps, args.warmup, rank, world, dist, cdev, with_roofline=True)
     extra = {}
-    if rank == 0:
-        k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms = roofline_pass(eng)
-        nw = (args.rows * args.cols + 63) // 64
-        bytes_per_launch, shape = algorithmic_bytes(kc, args.games, args.rows * args.cols, n_launch, nw)
-        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k_mcts_pmc.json")
-        if os.path.exists(pmc) and (args.games, args.rows, args.cols, args.sims) == (4096, 8, 8, 800):
-            traffic = json.load(open(pmc))["per_launch_bytes"]["traffic_corrected"]
-        roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": k_ms, "launches_timed": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "pmc_profile": "profiles/ (rocprofv3 --pmc passes are collected offline; see DESIGN.md)", **shape}
-        roof = roof_tree
-        if tower_ms is not None:
-            # dominant kernel of a step = the LDS-resident MFMA tower (csrc/yy_tower.hip): algorithmic FLOPs per
-            # board = stem with K padded to 16 + 2 convs per block, each 2*9*128*128*64
-            cells = args.rows * args.cols
-            tower_flops = (2 * 9 * 16 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)
-                           + (2 * 128 * 64 * cells if getattr(eng.evaluator, "fused_heads", False) else 0)) * args.games
-            ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            f32t = args.nn == "fp32t"
-            if f32t:   # exact-f32 kernel: K of the stem padded to 8, no fused heads
-                tower_flops = (2 * 9 * 8 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)) * args.games
-                ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            x3 = args.nn == "bf16x3"
-            if x3:     # split-bf16 kernel: K of the stem padded to 16, no fused heads
-                tower_flops = (2 * 9 * 16 * 128 * cells + 2 * args.blocks * (2 * 9 * 128 * 128 * cells)) * args.games
-                ach = tower_flops / (tower_ms * 1e-3) / 1e12
-            # split-bf16 issues three bf16 MFMAs per algorithmic multiply-add: its bound is a third of the bf16 peak
-            peak = MFMA_F32_PEAK_TFLOPS if f32t else (MFMA_BF16_PEAK_TFLOPS / 3 if x3 else MFMA_BF16_PEAK_TFLOPS)
-            name = "k_tower_f32 (stem + residual tower, exact f32 MFMA 32x32x2, activations LDS-resident)" if f32t else \
-                "k_tower_x3 (stem + residual tower, split-bf16: 3 bf16 MFMAs per product term, f32-grade accuracy; peak = bf16 MFMA peak / 3)" if x3 else \
-                {6: "k_towerq<6,8>", 8: "k_tower" if args.games > 512 else "k_towerq<8,%d>" % (1 if args.games <= 256 else 2), 12: "k_towerq<12,2>"}.get(args.rows, "k_tower") + \
-                " (stem + residual tower + 1x1 head convs, bf16 MFMA, activations LDS-resident)"
-            ttraffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same G, same kernel)
-            tpmc = os.path.join(ROOT, "profiles", "r01_k_tower_hbm_pmc.json")
-            if os.path.exists(tpmc) and not f32t and getattr(eng.evaluator, "fused_heads", False) and \
-                    (args.games, args.rows, args.cols, args.channels, args.blocks) == (4096, 8, 8, 128, 10):
-                ttraffic = json.load(open(tpmc))["per_launch_bytes"]["traffic_corrected"]
-            roof = {"bound": "mfma", "kernel": name,
-                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": ttraffic, "avg_launch_ms": tower_ms, "algorithmic_flops_per_launch": tower_flops}
-            extra["roofline_tree_kernel"] = roof_tree
-        A = args.rows * args.cols
-        Cc = args.channels
-        flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
-                      + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
-        extra = {**extra, "nn_forward_ms": nn_ms, "nn_tflops": flops_leaf * args.games / (nn_ms * 1e-3) / 1e12,
-                 "tree_kernel_ms": k_ms, "tree_kernel_only_expansions_per_s": kc["evals"] / max(n_launch, 1) / (k_ms * 1e-3),
-                 "eager_move_ms": eager_move_ms, "gather_s": gather_s, "examples_gathered": int(ex_all["states"].shape[0])}
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
-            cpub = cpu_baseline(args)
+    default_workload = (args.games, args.rows, args.cols, args.sims, args.channels, args.blocks) == (4096, 8, 8, 800, 128, 10)
+    if world == 1:
+        if args.secondary_nn not in ("none", args.nn):
+            leg = run_leg(args, args.secondary_nn, args.games, args.secondary_steps, 1, rank, world, dist, cdev, False)
+            extra["secondary"] = leg_summary(leg, "same workload, %s evaluator%s" % (
+                args.secondary_nn, "" if args.secondary_nn in FP32_GRADE else
+                ": REDUCED precision against the reference's float32 (not the headline; parity figures in "
+                "tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi)"))
+        over = args.oversubscribe if args.oversubscribe >= 0 else (4320 if default_workload and args.nn == "f16x3" else 0)
+        if over > 0:
+            leg = run_leg(args, args.nn, over, args.oversubscribe_steps, 1, rank, world, dist, cdev, False)
+            extra["oversubscribed"] = leg_summary(leg, f"headline evaluator with {over} concurrent games: the leaves that need "
+                                                       "an evaluation (terminal revisits do not) are compacted into ~4096-row launches = "
+                                                       "8 whole rounds of 2-board workgroups on 256 CUs")
+    cpub = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
+        cpub = cpu_baseline(args)
     if dist is not None:
         dist.barrier()
     if rank == 0:
-        sims_total = args.steps * args.sims * args.games * world
+        roof = main_leg.pop("roofline")
+        dt = main_leg["dt"]
         line = {
-            "metric": "self-play positions/sec (+ MCTS node-expansions/sec) at 800 sims, 8x8 board",
-            "value": positions_all / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"self-play positions/sec (+ MCTS node-expansions/sec) at {args.sims} sims, {args.rows}x{args.cols} board",
+            "value": main_leg["positions"] / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.nn, "data": "synthetic",
-            "expansions_per_s": evals_all / dt, "simulations_per_s": sims_total / dt,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.nn,
+            "dtype_note": FP32_GRADE.get(args.nn, "reduced-precision evaluator (the reference evaluates in float32)"),
+            "data": "synthetic",
+            "expansions_per_s": main_leg["evals"] / dt, "simulations_per_s": main_leg["sims_total"] / dt,
             "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
                                    f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
                                    f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
                        "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
                        "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
-            "roofline": roof, "cpu_baseline": cpub, **extra,
+            "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
+            **roof, **extra,
         }
         print(json.dumps(line))
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

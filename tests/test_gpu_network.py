@@ -320,7 +320,7 @@ def _module_f64(net, planes):
         return x, torch.softmax(logits, 1), value.reshape(-1)
 
 
-@pytest.mark.parametrize("R", [8])
+@pytest.mark.parametrize("R", [8, 6, 12])
 def test_split_f16_tower_kernel_is_float32_grade(R):
     """csrc/yy_tower_h3.hip (activations and weights as hi + lo*2^-11 float16 pairs, three f16 MFMAs per product term, two
     f32 accumulators) against the module evaluated in FLOAT64: 22 significant bits per operand, so the error must be that
@@ -331,7 +331,7 @@ def test_split_f16_tower_kernel_is_float32_grade(R):
     torch.backends.cudnn.allow_tf32 = False
     game = pkg.YinYangGame(R, R)
     rng = np.random.default_rng(6)
-    for blocks, G in ((1, 3), (10, 71)):
+    for blocks, G in ((1, 3), (10, 71 if R == 8 else 23)):
         net = _randomized_net(pkg, game, blocks, 2)
         boards = torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda()
         planes = pkg.engine.encode_planes(boards)
@@ -357,17 +357,18 @@ def test_split_f16_tower_kernel_is_float32_grade(R):
         assert torch.allclose(p.sum(1), torch.ones(G, device="cuda"), atol=1e-5)
 
 
-def test_split_f16_evaluator_row_compaction_is_bit_exact():
+@pytest.mark.parametrize("R", [8, 6, 12])
+def test_split_f16_evaluator_row_compaction_is_bit_exact(R):
     """evaluator(planes, needs_eval): the flagged rows hold exactly the bits of the full evaluation (a board's output does
     not depend on the workgroup / row it is evaluated in), the other rows are zero; every pattern incl. none and all."""
     import torch
     import yinyang_game_alphazero_amd as pkg
-    game = pkg.YinYangGame(8, 8)
+    game = pkg.YinYangGame(R, R)
     net = _randomized_net(pkg, game, 2, 3)
     ev = pkg.BatchedEvaluator(net, "f16x3")
     rng = np.random.default_rng(9)
     for G in (1, 2, 5, 64, 333):
-        planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
+        planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
         p_all, v_all = ev(planes)
         for frac in (0.0, 0.5, 0.94, 1.0):
             flags = torch.from_numpy((rng.random(G) < frac).astype(np.uint8)).cuda()

@@ -32,7 +32,7 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"),
+    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"), os.path.join(CSRC, "yy_tower_h3q.hip"),
             os.path.join(CSRC, "yy_bitboard.h"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO

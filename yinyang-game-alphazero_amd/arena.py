@@ -212,7 +212,7 @@ class AlphaZero:
 
     def __init__(self, game, model_dir="models", data_dir="data", num_iterations=100, num_episodes=100,
                  num_simulations=800, num_epochs=10, temperature_threshold=10, update_threshold=0.6, num_workers=1,
-                 mcts_threads=1, arena_games=40, nn_mode="bf16", num_channels=128, num_res_blocks=10,
+                 mcts_threads=1, arena_games=40, nn_mode="auto", num_channels=128, num_res_blocks=10,
                  concurrent_games=4096, device=None, lr=0.001, batch_size=64):
         self.game, self.model_dir, self.data_dir = game, model_dir, data_dir
         self.num_iterations, self.num_episodes, self.num_simulations = num_iterations, num_episodes, num_simulations
@@ -306,7 +306,7 @@ class AlphaZero:
         return self.history
 
 
-def evaluate_vs_random(game, model_path, num_games=10, num_simulations=800, nn_mode="bf16", device=None,
+def evaluate_vs_random(game, model_path, num_games=10, num_simulations=800, nn_mode="auto", device=None,
                        num_channels=128, num_res_blocks=10):
     """`--mode evaluate` (train_alphazero.py:124-243): the model against RandomPlayer, alternating colours."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -653,7 +653,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             best = (mx == 0u || mi == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)mi;
         }
         if (mx == 0u) best = 0x7FFFFFFF;
-        if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = st->err_ever = 1; break; }  // NaN priors
+        if (best == 0x7FFFFFFF) { kind = K_NONE; if (lane == 0) st->err = st->err_ever = 1; break; }  // no selectable child
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)bw, best & 63);
         s_carry = (int)__builtin_amdgcn_readlane((int)bn, best & 63) - 1;
         if (lane == 0) path[depth] = first + best;
@@ -800,11 +800,13 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                 mix = any != 0;
             }
             int base = n_edges;
+            bool bad = false;   // a NaN prior (python: `score > best` is never true for it, select_child returns None and the game raises)
 #pragma unroll
             for (int j = 0; j < NW; j++) {
                 const int cell = j * 64 + lane;
                 if ((mask.w[j] >> lane) & 1) {
                     float p = policy[(size_t)g * A + cell];
+                    bad |= (p != p);
                     if (mix) {                                                      // mcts.py:310-312
                         const float kp = __fmul_rn(keep, p);
                         p = (float)__dadd_rn((double)kp, __dmul_rn(d.eps, noise[(size_t)g * A + cell]));
@@ -813,6 +815,10 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                         make_uint4(__float_as_uint(p), 0u, 0u, CHILD_NONE | ((uint32_t)cell << 24));
                 }
                 base += yy_popc64(mask.w[j]);
+            }
+            if (__ballot(bad)) {
+                if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
+                return;
             }
             if (lane == 0) {
                 nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, 0, lplayer), 0u, 0u);

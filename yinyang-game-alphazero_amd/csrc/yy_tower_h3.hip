@@ -83,6 +83,12 @@ __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
+// packed (hi, hi), (lo, lo) -> two f32: hi + lo * 2^-11
+__device__ __forceinline__ f32x2 join_pair(const uint32_t hi, const uint32_t lo) {
+    const f32x2 h = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
+    const f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
+    return (f32x2){__builtin_fmaf(l.x, H_LO_INV, h.x), __builtin_fmaf(l.y, H_LO_INV, h.y)};
+}
 
 // The ring protocol of one chunk.  Invariant on entry: chunk `chunk` is visible in its slot to every wave (or becomes so at
 // the barrier below when `first`).  Makes chunk+1 visible (counted vmcnt + barrier), then refills the slot chunk-1 used.
@@ -352,12 +358,8 @@ k_tower_h3(const float *__restrict__ planes, const unsigned char *__restrict__ w
             const int cell = p >> 5, ch4 = p & 31;
             const u32x2 ph = *(const u32x2 *)(lds + row_off(board, 0, cell) + ch4 * 8);
             const u32x2 pl = *(const u32x2 *)(lds + row_off(board, 1, cell) + ch4 * 8);
-            const f32x2 h01 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph[0]), f32x2);
-            const f32x2 h23 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph[1]), f32x2);
-            const f32x2 l01 = __builtin_convertvector(__builtin_bit_cast(f16x2, pl[0]), f32x2);
-            const f32x2 l23 = __builtin_convertvector(__builtin_bit_cast(f16x2, pl[1]), f32x2);
-            const f32x4 v = {__builtin_fmaf(l01[0], H_LO_INV, h01[0]), __builtin_fmaf(l01[1], H_LO_INV, h01[1]),
-                             __builtin_fmaf(l23[0], H_LO_INV, h23[0]), __builtin_fmaf(l23[1], H_LO_INV, h23[1])};
+            const f32x2 v01 = join_pair(ph.x, pl.x), v23 = join_pair(ph.y, pl.y);
+            const f32x4 v = {v01.x, v01.y, v23.x, v23.y};
             *(f32x4 *)(out + ((size_t)gb * H_CELLS + cell) * H_CH + ch4 * 4) = v;
         }
     }
@@ -365,13 +367,19 @@ k_tower_h3(const float *__restrict__ planes, const unsigned char *__restrict__ w
 
 }   // namespace th3
 
+extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, const float *bias, float *out, float *out_heads,
+                                   const int *rows, const int *n_rows, int G, int R, int n_layers, yy_stream_t s);   // yy_tower_h3q.hip
+
 static int launch_h3(const float *planes, const void *weights, const float *bias, float *out, float *out_heads, const int *rows,
                      const int *n_rows, int G, int R, int C, int channels, int n_layers, yy_stream_t s) {
     if (G == 0) return YY_OK;
     if (!planes || !weights || !bias || (!out && !out_heads) || G < 0 || (rows && !n_rows))
         return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_f16x3: bad argument");
-    if (R != 8 || C != 8 || channels != H_CH || n_layers < 1 || n_layers + (out_heads ? 1 : 0) > H_MAX_LAYERS || (n_layers & 1) == 0)
-        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: needs 8x8 boards, 128 channels, at most 10 residual blocks");
+    if (R != C || (R != 6 && R != 8 && R != 12) || channels != H_CH || n_layers < 1 ||
+        n_layers + (out_heads ? 1 : 0) > H_MAX_LAYERS || (n_layers & 1) == 0)
+        return yy_tower_set_err(YY_E_UNSUPPORTED,
+                                "yy_nn_tower_f16x3: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
+    if (R != 8) return yy_tower_h3q_launch(planes, weights, bias, out, out_heads, rows, n_rows, G, R, n_layers, s);
     th3::k_tower_h3<<<dim3((G + H_TB - 1) / H_TB), dim3(256), 0, (hipStream_t)s>>>(planes, (const unsigned char *)weights, bias, out,
                                                                                  out_heads, rows, n_rows, G, n_layers);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3: launch failed");

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-H3_BOARDS = ((8, 8),)      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
+H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
 INPUT_PLANES = 5
@@ -273,10 +273,23 @@ def pack_heads(net):
     return chunk.to(torch.bfloat16).view(torch.int16).contiguous(), bias
 
 
+def reference_precision_mode(net):
+    """The fastest evaluator mode that is float32-ACCURATE for this network (the reference evaluates in float32,
+    neural_network.py:125-154): "f16x3" where the split-f16 tower kernels cover the shape, else "fp32" (the module itself)."""
+    ok = (tuple(net.board_size) in H3_BOARDS and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10
+          and net.policy_conv.out_channels == 32)
+    return "f16x3" if ok else "fp32"
+
+
 class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
-    mode "fp32": the module as is (parity path: same arithmetic as predict()).
+    mode "auto" (default): `reference_precision_mode(net)` -- "f16x3" where the kernels cover the shape, else "fp32".
+    mode "f16x3": float32 ACCURACY on the f16 matrix cores (csrc/yy_tower_h3.hip / yy_tower_h3q.hip): activations and weights
+    as hi + lo*2^-11 float16 pairs (22 significant bits), three MFMAs per product term, f32 accumulation / bias / residual,
+    1x1 head convs fused, FC heads as float32 GEMMs + one finish kernel.  Searches driven by it return the reference's visit
+    counts (tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi); supports row compaction.
+    mode "fp32": the module as is (same arithmetic as predict()).
     mode "fp32t": the same float32 weights, but the stem + residual tower run in the hand-written exact-f32 MFMA kernel
     (csrc/yy_tower_f32.hip; 8x8 boards, 128 channels); heads by torch in float32.  Differs from "fp32" only by summation order.
     mode "bf16x3": float32-grade accuracy on the bf16 matrix cores (csrc/yy_tower_x3.hip): activations and weights as
@@ -289,8 +302,10 @@ class BatchedEvaluator:
     the 3-4 elementwise kernels PyTorch would launch.
     """
 
-    def __init__(self, net, mode="fp32", fused_epilogue=True, tower=True, fused_heads=True):
+    def __init__(self, net, mode="auto", fused_epilogue=True, tower=True, fused_heads=True):
         self.net = net.eval()
+        if mode == "auto":            # reference precision, fastest available kernel
+            mode = reference_precision_mode(net)
         self.mode = mode
         self.device = next(net.parameters()).device
         self.fused = bool(fused_epilogue) and mode == "bf16"

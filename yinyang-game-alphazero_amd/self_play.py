@@ -446,7 +446,7 @@ class SelfPlayManager:
     def __init__(self, game, model_path, num_workers=1, num_simulations=800, games_per_worker=1,
                  temperature_threshold=10, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0,
                  mcts_parallel=1, concurrent_games=4096, board_semantics="copied", reference_quirks=False,
-                 nn_mode="bf16", seed=0, num_channels=128, num_res_blocks=10):
+                 nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10):
         self.game, self.model_path = game, model_path
         self.num_workers, self.games_per_worker = num_workers, games_per_worker
         self.num_simulations, self.temperature_threshold = num_simulations, temperature_threshold
