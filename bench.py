@@ -103,6 +103,7 @@ def stagger_start(eng, seed):
     ply[ended] = 0
     eng.boards, eng.players, eng.ply = boards, players.contiguous(), ply
     eng.alive[:] = True
+    eng.n_alive = G
     eng.n_ex[:] = 0
     eng.game_id = torch.arange(G, device=dev, dtype=torch.int64)
     eng.games_started = G

@@ -232,6 +232,11 @@ int yy_nn_tower_heads_f16x3(const float *planes, const void *weights, const floa
                             const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
                             int channels, int n_layers, yy_stream_t stream);
 
+/* 8x8 only: which of the two equivalent workgroup shapes the split-f16 launches use -- 0 = wave = board x output-channel half
+ * (yy_tower_h3.hip), 1 = wave = output-channel quarter x both boards with wave-private weight rings (yy_tower_h3q.hip).
+ * Identical bits; exported for A/B timing. */
+int yy_nn_tower_f16x3_set_form8(int form);
+
 /* float32 head finish (neural_network.py:115, 120-121, 152): logits float32 [G,A] (policy_fc output, bias added), hidden
  * float32 [G,H] (value_fc1 output, bias added) of dense row i -> policy[g] = softmax(logits[i]),
  * value[g] = tanh(relu(hidden[i]) . w2 + b2), g = rows ? rows[i] : i, for i < (n_rows ? *n_rows : G). */
@@ -243,6 +248,23 @@ int yy_nn_head_finish_f32(const float *logits, const float *hidden, int G, int A
  * selected leaf needs an evaluation: yy_mcts_select / yy_mcts_step write these flags; a terminal revisit does not,
  * mcts.py:365-366).  All pointers are device pointers. */
 int yy_compact_rows(const uint8_t *flags, int G, int32_t *rows, int32_t *n, yy_stream_t stream);
+
+/* ------------------------------------------------------------------ episode-loop random draws
+ * Counter-based (Philox4x32-10) replacements of the two draws the reference takes from numpy's global stream, keyed by
+ * (seed, GLOBAL game index, ply, purpose, element) so that a game's transcript does not depend on its slot, on the batch
+ * size, on refill order or on the number of ranks.  All pointers are device pointers.
+ *
+ * yy_selfplay_root_noise: np.random.dirichlet([alpha] * k) over the k legal moves (ai/mcts.py:298-312), for the games with
+ * draw[g] != 0: noise float64 [G,A], zero rows elsewhere (yy_mcts_expand_root treats an all-zero row as "no noise"). */
+int yy_selfplay_root_noise(uint64_t seed, const int64_t *game_id, const int32_t *ply, const uint8_t *draw,
+                           const uint8_t *mask, int G, int A, double alpha, double *noise, yy_stream_t stream);
+
+/* yy_selfplay_sample_actions: the move choice of SelfPlayWorker.play_game (ai/self_play.py:143-160) for the games with
+ * searching[g] != 0 (action -1 otherwise): ply < temperature_threshold -> sample from pi * mask renormalised (uniform over
+ * the legal moves when that sum is 0); else a uniformly random member of argmax(pi).  pi float64 [G,A], mask uint8 [G,A]. */
+int yy_selfplay_sample_actions(uint64_t seed, const int64_t *game_id, const int32_t *ply,
+                               const uint8_t *searching, const double *pi, const uint8_t *mask, int G, int A,
+                               int temperature_threshold, int32_t *action, yy_stream_t stream);
 
 #ifdef __cplusplus
 }

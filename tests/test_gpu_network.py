@@ -379,3 +379,27 @@ def test_split_f16_evaluator_row_compaction_is_bit_exact(R):
             keep = flags.bool()
             assert torch.equal(p[keep], p_all[keep]) and torch.equal(v[keep], v_all[keep])
             assert float(p[~keep].abs().sum()) == 0.0 and float(v[~keep].abs().sum()) == 0.0
+
+
+def test_split_f16_8x8_kernel_forms_give_identical_bits():
+    """The two 8x8 workgroup shapes of the split-f16 tower (board x cout-half waves with a shared weight ring; cout-quarter
+    waves with wave-private weight rings) accumulate every output element in the same order: identical bits."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd._lib import lib
+    game = pkg.YinYangGame(8, 8)
+    net = _randomized_net(pkg, game, 10, 4)
+    ev = pkg.BatchedEvaluator(net, "f16x3")
+    rng = np.random.default_rng(12)
+    planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(77, 8, 8)).astype(np.int8)).cuda())
+    outs = []
+    try:
+        for form in (0, 1):
+            lib().yy_nn_tower_f16x3_set_form8(form)
+            feats = pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
+            n_tower = 9 + 36 * (ev.h3_layers - 1)
+            x = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), ev.h3_b[:ev.h3_layers].contiguous(), ev.h3_layers)
+            outs.append((feats.clone(), x.clone()))
+    finally:
+        lib().yy_nn_tower_f16x3_set_form8(0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -366,3 +366,98 @@ def test_engine_is_reproducible_for_a_seed(pkg):
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
     assert runs[0]["states"].shape != runs[2]["states"].shape or not torch.equal(runs[0]["states"], runs[2]["states"])
+
+
+# ---- per-game counter-based random streams (csrc/yy_selfplay.hip)
+def test_sample_actions_kernel_equals_host_restatement(pkg):
+    """yy_selfplay_sample_actions against tests/philox_ref.py (Philox4x32-10 pinned by Random123's known answers): same
+    uniform, same float64 running sums in the same order -> the same action, for temperature 1 (incl. zero-mass rows ->
+    uniform over the legal moves), temperature 0 (ties), idle games (-1)."""
+    import torch
+    from philox_ref import sample_action
+    rng = np.random.default_rng(3)
+    for A in (9, 36, 64, 144):
+        G = 96
+        pi = rng.random((G, A)) * (rng.random((G, A)) < 0.3)
+        pi[::7] = np.round(pi[::7] * 4) / 4            # ties
+        mask = (rng.random((G, A)) < 0.5).astype(np.uint8)
+        pi[5] = 0.0                                     # no mass on the legal moves
+        mask[6] = 0
+        pi = pi / np.maximum(pi.sum(1, keepdims=True), 1e-300)
+        ply = rng.integers(0, 20, size=G).astype(np.int32)
+        gid = rng.integers(0, 2 ** 40, size=G).astype(np.int64)
+        searching = (rng.random(G) < 0.8).astype(np.uint8)
+        seed = 1000 + A
+        got = pkg.engine.sample_actions(seed, torch.from_numpy(gid).cuda(), torch.from_numpy(ply).cuda(),
+                                        torch.from_numpy(searching).cuda(), torch.from_numpy(pi).cuda(),
+                                        torch.from_numpy(mask).cuda(), 10).cpu().numpy()
+        for g in range(G):
+            want = sample_action(seed, int(gid[g]), int(ply[g]), pi[g], mask[g], 10) if searching[g] else -1
+            assert got[g] == want, (A, g)
+            if searching[g] and ply[g] < 10 and mask[g].any():
+                assert mask[g][got[g]] == 1
+
+
+def test_root_noise_is_a_dirichlet_draw_per_game(pkg):
+    """noise rows: zero for games that do not draw and on illegal cells, sum to 1 over the legal cells, depend only on
+    (seed, game id, ply) -- not on the row or the batch -- and have the Dirichlet(0.3) component mean 1/k and variance
+    (1/k)(1-1/k)/(0.3k+1) within sampling error."""
+    import torch
+    rng = np.random.default_rng(4)
+    G, A, k = 4096, 64, 16
+    mask = np.zeros((G, A), np.uint8)
+    mask[:, :k] = 1
+    gid = torch.arange(G, dtype=torch.int64, device="cuda")
+    ply = torch.zeros(G, dtype=torch.int32, device="cuda")
+    draw = torch.ones(G, dtype=torch.uint8, device="cuda")
+    draw[::5] = 0
+    n = pkg.engine.root_noise(7, gid, ply, draw, torch.from_numpy(mask).cuda(), 0.3).cpu().numpy()
+    on = draw.cpu().numpy().astype(bool)
+    assert (n[~on] == 0).all() and (n[:, k:] == 0).all() and (n >= 0).all()
+    assert np.allclose(n[on].sum(1), 1.0, atol=1e-12)
+    x = n[on][:, :k]
+    assert abs(x.mean() - 1 / k) < 1e-3
+    var = (1 / k) * (1 - 1 / k) / (0.3 * k + 1)
+    assert abs(x.var() - var) < 0.05 * var
+    # the same games in another order / batch: identical rows
+    perm = torch.from_numpy(rng.permutation(G)[:500]).cuda()
+    n2 = pkg.engine.root_noise(7, gid[perm].contiguous(), ply[perm].contiguous(), draw[perm].contiguous(),
+                               torch.from_numpy(mask).cuda()[perm].contiguous(), 0.3).cpu().numpy()
+    assert np.array_equal(n2, n[perm.cpu().numpy()])
+    n3 = pkg.engine.root_noise(8, gid, ply, draw, torch.from_numpy(mask).cuda(), 0.3).cpu().numpy()
+    assert not np.array_equal(n3, n)
+
+
+def test_game_transcripts_do_not_depend_on_slot_batch_or_world_size(pkg):
+    """Game g's (states, pi, z) must be identical whether it is played in a batch of 64 slots, through 16 refilled slots
+    (different slot, different neighbours, packed tail), or by one of two 'ranks' that each play every second game
+    (first_game_index / stride = (r, 2)): noise and moves come from (seed, game id, ply) alone."""
+    import torch
+    from hash_eval import hash_eval_torch
+    game = pkg.YinYangGame(6, 6)
+    ev = lambda planes: hash_eval_torch(planes, 10, 11)
+
+    def play(G, n, first, stride):
+        eng = pkg.SelfPlayEngine(game, ev, num_simulations=20, concurrent_games=G, seed=1000, first_game_index=first,
+                                 game_index_stride=stride, row_tiers=(8, 16, 32))
+        ex = eng.run(n)
+        eng.close()
+        out = {}
+        gid, ply = ex["game_id"].cpu().numpy(), ex["ply"].cpu().numpy()
+        st, pi, z = ex["states"].cpu().numpy(), ex["policies"].cpu().numpy(), ex["values"].cpu().numpy()
+        for g in np.unique(gid):
+            sel = np.flatnonzero(gid == g)
+            sel = sel[np.argsort(ply[sel])]
+            out[int(g)] = (st[sel], pi[sel], z[sel])
+        return out
+
+    ref = play(64, 64, 0, 1)
+    assert sorted(ref) == list(range(64))
+    assert len({v[0].tobytes() for v in ref.values()}) > 32          # the games really differ from one another
+    small = play(16, 64, 0, 1)
+    two = {**play(32, 32, 0, 2), **play(32, 32, 1, 2)}
+    for other in (small, two):
+        assert sorted(other) == sorted(ref)
+        for g in ref:
+            for a, b in zip(ref[g], other[g]):
+                assert np.array_equal(a, b), g

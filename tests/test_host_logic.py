@@ -242,3 +242,12 @@ def test_game_helpers_match_reference_golden():
             assert game.stringRepresentation(lb) == z[f"boards_{R}"][i].tobytes()
         assert game._action_to_coords(R + 1) == (1, 1) and game._coords_to_action(2, 3) == 2 * R + 3
         assert game.getBoardSize() == (R, R) and game.getActionSize() == R * R
+
+
+def test_philox_restatement_known_answers():
+    """Random123's published Philox4x32-10 known-answer vectors pin the host restatement the GPU streams are checked against."""
+    from philox_ref import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

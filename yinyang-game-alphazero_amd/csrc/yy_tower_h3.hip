@@ -370,6 +370,12 @@ k_tower_h3(const float *__restrict__ planes, const unsigned char *__restrict__ w
 extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, const float *bias, float *out, float *out_heads,
                                    const int *rows, const int *n_rows, int G, int R, int n_layers, yy_stream_t s);   // yy_tower_h3q.hip
 
+static int g_h3_form8 = 0;   // 8x8 kernel form: 0 = board x cout-half waves (this file), 1 = cout-quarter waves (yy_tower_h3q.hip)
+extern "C" int yy_nn_tower_f16x3_set_form8(int form) {   // A/B measurements (tools/eval_micro.py); same bits either way
+    g_h3_form8 = form ? 1 : 0;
+    return YY_OK;
+}
+
 static int launch_h3(const float *planes, const void *weights, const float *bias, float *out, float *out_heads, const int *rows,
                      const int *n_rows, int G, int R, int C, int channels, int n_layers, yy_stream_t s) {
     if (G == 0) return YY_OK;
@@ -379,7 +385,7 @@ static int launch_h3(const float *planes, const void *weights, const float *bias
         n_layers + (out_heads ? 1 : 0) > H_MAX_LAYERS || (n_layers & 1) == 0)
         return yy_tower_set_err(YY_E_UNSUPPORTED,
                                 "yy_nn_tower_f16x3: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
-    if (R != 8) return yy_tower_h3q_launch(planes, weights, bias, out, out_heads, rows, n_rows, G, R, n_layers, s);
+    if (R != 8 || g_h3_form8 == 1) return yy_tower_h3q_launch(planes, weights, bias, out, out_heads, rows, n_rows, G, R, n_layers, s);
     th3::k_tower_h3<<<dim3((G + H_TB - 1) / H_TB), dim3(256), 0, (hipStream_t)s>>>(planes, (const unsigned char *)weights, bias, out,
                                                                                  out_heads, rows, n_rows, G, n_layers);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3: launch failed");

@@ -26,8 +26,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define HQ_CH 128
 #define HQ_ROW_BYTES 272
 #define HQ_CHUNK_BYTES 16384
-#define HQ_NSLOT 4
-#define HQ_MAX_LAYERS 23
+#define HQ_MAX_LAYERS 22                     // bias rows: 21 tower layers + 1 head row
 #define HQ_LO_SCALE 2048.0f
 #define HQ_LO_INV 0.00048828125f
 
@@ -35,15 +34,15 @@ extern "C" int yy_tower_set_err(int code, const char *msg);
 
 namespace thq {
 
-template <int R_, int TB_> struct Geo {
-    static constexpr int R = R_, TB = TB_, CELLS = R_ * R_, NCOL = TB_ * R_ * R_, CT = (NCOL + 31) / 32;
+template <int R_, int TB_, int NSLOT_> struct Geo {
+    static constexpr int R = R_, TB = TB_, NSLOT = NSLOT_, CELLS = R_ * R_, NCOL = TB_ * R_ * R_, CT = (NCOL + 31) / 32;
     // one part (hi or lo) of every column + a zero row behind it: the lo row of ANY hi row (the zero row included) sits
     // PART_BYTES further, so a lane keeps one base per tile and the lo read is an immediate offset
     static constexpr int PART_BYTES = (NCOL + 1) * HQ_ROW_BYTES;
     static constexpr int ZERO_OFF = NCOL * HQ_ROW_BYTES;
     static constexpr int ACT_BYTES = 2 * PART_BYTES;
     static constexpr int RING_OFF = ACT_BYTES;
-    static constexpr int BIAS_OFF = RING_OFF + HQ_NSLOT * HQ_CHUNK_BYTES;
+    static constexpr int BIAS_OFF = RING_OFF + NSLOT * HQ_CHUNK_BYTES;
     static constexpr int LDS_BYTES = BIAS_OFF + HQ_MAX_LAYERS * HQ_CH * 4;
     static_assert(PART_BYTES + 256 < 65536, "lo offset must fit the ds_read immediate");
     static_assert(LDS_BYTES <= 163840, "LDS budget");
@@ -53,6 +52,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 template <class GEO>
 __device__ __forceinline__ void issue_chunk(const unsigned char *wchunk, unsigned char *lds, int slot, int wave, int lane) {
@@ -76,21 +76,29 @@ __device__ __forceinline__ f32x2 join_pair(const uint32_t hi, const uint32_t lo)
     const f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
     return (f32x2){__builtin_fmaf(l.x, HQ_LO_INV, h.x), __builtin_fmaf(l.y, HQ_LO_INV, h.y)};
 }
-// ring protocol of one chunk (see yy_tower_h3.hip): makes chunk+1 visible, then refills the slot chunk-1 used
+// Ring protocol of one chunk.  The chunk layout [ks 2][part 2][nt 4][1 KB] and the piece order of issue_chunk make wave w
+// load exactly the four 1 KB pieces (nt == w) that wave w itself reads: the weight ring is WAVE-PRIVATE, so a chunk costs
+// the wave one counted vmcnt wait and NO workgroup barrier (barriers remain only around the epilogue, where the waves
+// exchange activations).  Invariant on entry: the wave's pieces of `chunk` have landed.  Waits for its pieces of chunk+1
+// (the last k-step of a chunk prefetches the next chunk's first fragments), then refills the slot chunk-1 used -- every read of
+// that slot by this wave has returned (its fragments were consumed by MFMAs earlier in program order).
 template <class GEO>
 __device__ __forceinline__ void chunk_sync(const unsigned char *weights, unsigned char *lds, int chunk, int n_chunks, bool first,
                                            int wave, int lane) {
+    constexpr int AHEAD = GEO::NSLOT - 1;                 // chunks issued beyond the current one
     if (chunk + 1 < n_chunks) {
-        if (n_chunks - 2 - chunk >= 1) wait_vmcnt<4>();   // chunk+2 may stay in flight
+        const int newer = min(AHEAD - 2, n_chunks - 2 - chunk);   // chunks younger than chunk+1 that may stay in flight
+        if (newer >= 2) wait_vmcnt<8>();
+        else if (newer == 1) wait_vmcnt<4>();
         else wait_vmcnt<0>();
     }
-    if (chunk + 1 < n_chunks || first) {
+    if (first) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();   // the previous layer's epilogue (or the prologue) is visible to every wave
         asm volatile("" ::: "memory");
     }
-    if (chunk + 3 < n_chunks)
-        issue_chunk<GEO>(weights + (size_t)(chunk + 3) * HQ_CHUNK_BYTES, lds, (chunk + 3) % HQ_NSLOT, wave, lane);
+    if (chunk + AHEAD < n_chunks)
+        issue_chunk<GEO>(weights + (size_t)(chunk + AHEAD) * HQ_CHUNK_BYTES, lds, (chunk + AHEAD) % GEO::NSLOT, wave, lane);
 }
 
 template <int CT> struct Frags {
@@ -170,7 +178,7 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc1)[GEO::CT], f32x16 (&acc2
     for (int i = 0; i < NCH; i++, chunk++) {
         const int quarter = STEM ? 0 : (i & 3);
         chunk_sync<GEO>(weights, lds, chunk, n_chunks, i == 0, wave, lane);
-        if (i == 0) load_frags<GEO>(cur, lds, chunk % HQ_NSLOT, 0, 0, cb, nh, lane);
+        if (i == 0) load_frags<GEO>(cur, lds, chunk % GEO::NSLOT, 0, 0, cb, nh, lane);
         const bool last = (i == NCH - 1);
         const int ni = last ? i : i + 1;
         uint32_t ncb[CT];
@@ -180,8 +188,8 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc1)[GEO::CT], f32x16 (&acc2
         for (int ks = 0; ks < KS; ks++) {
             Frags<CT> nxt;
             const bool has_next = (ks + 1 < KS) || !last;
-            if (ks + 1 < KS) load_frags<GEO>(nxt, lds, chunk % HQ_NSLOT, quarter, ks + 1, cb, nh, lane);
-            else if (!last) load_frags<GEO>(nxt, lds, (chunk + 1) % HQ_NSLOT, nquarter, 0, ncb, nh, lane);
+            if (ks + 1 < KS) load_frags<GEO>(nxt, lds, chunk % GEO::NSLOT, quarter, ks + 1, cb, nh, lane);
+            else if (!last) load_frags<GEO>(nxt, lds, (chunk + 1) % GEO::NSLOT, nquarter, 0, ncb, nh, lane);
             if (i == 0 && ks == 0) mma_ct<CT, true>(acc1, acc2, cur);
             else mma_ct<CT, false>(acc1, acc2, cur);
             if (has_next) {
@@ -194,12 +202,12 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc1)[GEO::CT], f32x16 (&acc2
     }
 }
 
-template <int R_, int TB_>
+template <int R_, int TB_, int NSLOT_>
 __global__ void __launch_bounds__(256, 1)
 k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
             float *__restrict__ out, float *__restrict__ out_heads, const int *__restrict__ rows,
             const int *__restrict__ n_rows, int G, int n_layers) {
-    using GEO = Geo<R_, TB_>;
+    using GEO = Geo<R_, TB_, NSLOT_>;
     constexpr int CT = GEO::CT, CELLS = GEO::CELLS, NCOL = GEO::NCOL, TB = GEO::TB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GEO::LDS_BYTES];
     const int n_live = n_rows ? min(*n_rows, G) : G;
@@ -236,9 +244,9 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
     const int n_tower = 9 + 36 * (n_layers - 1);
     const int n_chunks = n_tower + (out_heads ? 2 : 0);
 #pragma unroll
-    for (int pc = 0; pc < 3; pc++)
-        if (pc < n_chunks) issue_chunk<GEO>(weights + (size_t)pc * HQ_CHUNK_BYTES, lds, pc % HQ_NSLOT, wave, lane);
-    if (n_chunks >= 3) wait_vmcnt<8>();
+    for (int pc = 0; pc < GEO::NSLOT - 1; pc++)
+        if (pc < n_chunks) issue_chunk<GEO>(weights + (size_t)pc * HQ_CHUNK_BYTES, lds, pc % GEO::NSLOT, wave, lane);
+    if (n_chunks >= GEO::NSLOT - 1) wait_vmcnt<4 * (GEO::NSLOT - 2)>();   // this wave's pieces of chunk 0
     else wait_vmcnt<0>();
 
     LaneGeo<GEO> geo;
@@ -293,7 +301,7 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
 #pragma unroll
         for (int hc = 0; hc < 2; hc++, chunk++) {
             chunk_sync<GEO>(weights, lds, chunk, n_chunks, hc == 0, wave, lane);
-            const unsigned char *hw = lds + GEO::RING_OFF + (chunk % HQ_NSLOT) * HQ_CHUNK_BYTES + (h * 32 + c) * 16 + head * 1024;
+            const unsigned char *hw = lds + GEO::RING_OFF + (chunk % GEO::NSLOT) * HQ_CHUNK_BYTES + (h * 32 + c) * 16 + head * 1024;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 const f16x8 wh = __builtin_bit_cast(f16x8, *(const u32x4 *)(hw + ks * 4096));
@@ -346,19 +354,21 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
 }   // namespace thq
 
-template <int R_, int TB_>
+template <int R_, int TB_, int NSLOT_>
 static int launch_hq(const float *planes, const void *weights, const float *bias, float *out, float *out_heads, const int *rows,
                      const int *n_rows, int G, int n_layers, yy_stream_t s) {
-    thq::k_tower_h3q<R_, TB_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
+    thq::k_tower_h3q<R_, TB_, NSLOT_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
         planes, (const unsigned char *)weights, bias, out, out_heads, rows, n_rows, G, n_layers);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3: launch failed");
     return YY_OK;
 }
 
-// called by yy_tower_h3.hip for R = 6 (four boards per workgroup) and R = 12 (one board per workgroup)
+// called by yy_tower_h3.hip: R = 6 (four boards per workgroup), 12 (one board per workgroup), 8 (two boards per workgroup)
 extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, const float *bias, float *out, float *out_heads,
                                    const int *rows, const int *n_rows, int G, int R, int n_layers, yy_stream_t s) {
-    if (R == 6) return launch_hq<6, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-    if (R == 12) return launch_hq<12, 1>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (n_layers + (out_heads ? 1 : 0) > HQ_MAX_LAYERS) return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: too many layers");
+    if (R == 6) return launch_hq<6, 4, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (R == 12) return launch_hq<12, 1, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (R == 8) return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
     return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: board size");
 }

@@ -273,6 +273,36 @@ def head_finish(h, A, w2, b2):
     return policy, value
 
 
+# ------------------------------------------------------------------ episode-loop random draws (csrc/yy_selfplay.hip)
+def root_noise(seed, game_id, ply, draw, mask, alpha):
+    """Dirichlet(alpha) noise over the legal cells of the games with draw != 0, keyed by (seed, game_id, ply): float64 [G,A]."""
+    G, A = mask.shape
+    _need(game_id, torch.int64, (G,), "game_id")
+    _need(ply, torch.int32, (G,), "ply")
+    _need(draw, torch.uint8, (G,), "draw")
+    _need(mask, torch.uint8, (G, A), "mask")
+    out = torch.empty((G, A), dtype=torch.float64, device=mask.device)
+    with torch.cuda.device(mask.device):
+        check(lib().yy_selfplay_root_noise(ct.c_uint64(int(seed) & (2 ** 64 - 1)), _p(game_id), _p(ply), _p(draw), _p(mask), G, A,
+                                           float(alpha), _p(out), _stream()))
+    return out
+
+
+def sample_actions(seed, game_id, ply, searching, pi, mask, temperature_threshold):
+    """The move choice of play_game (self_play.py:143-160), keyed by (seed, game_id, ply): int32 [G], -1 where not searching."""
+    G, A = mask.shape
+    _need(game_id, torch.int64, (G,), "game_id")
+    _need(ply, torch.int32, (G,), "ply")
+    _need(searching, torch.uint8, (G,), "searching")
+    _need(pi, torch.float64, (G, A), "pi")
+    _need(mask, torch.uint8, (G, A), "mask")
+    out = torch.empty(G, dtype=torch.int32, device=mask.device)
+    with torch.cuda.device(mask.device):
+        check(lib().yy_selfplay_sample_actions(ct.c_uint64(int(seed) & (2 ** 64 - 1)), _p(game_id), _p(ply), _p(searching), _p(pi),
+                                               _p(mask), G, A, int(temperature_threshold), _p(out), _stream()))
+    return out
+
+
 # ------------------------------------------------------------------ batched MCTS context
 class BatchedMCTS:
     """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate

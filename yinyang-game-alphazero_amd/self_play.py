@@ -135,8 +135,8 @@ class SelfPlayEngine:
         self.ctx = engine.BatchedMCTS(self.G, self.R, self.C, self.sims, cpuct=cpuct, aliased=self.aliased,
                                       rowcol=self.rowcol, device=self.device)
         self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(int(seed))
+        self.seed = int(seed)                      # key of the per-game counter streams (csrc/yy_selfplay.hip)
+        self.n_alive = 0                           # live games, tracked on the host (no device read needed)
         self.first_game_index, self.stride = int(first_game_index), int(game_index_stride)
         # a game has at most A placements; passes never add examples.  Literal quirk mode can make
         # no-op moves (illegal placements), so leave generous room there.
@@ -157,6 +157,7 @@ class SelfPlayEngine:
         self.games_target = 0
         self.positions = 0
         self._ar = torch.arange(G, device=dev)
+        self._ones = torch.ones(G, dtype=torch.int8, device=dev)
         # draining batch: once no new game will start, live games are packed to the front and only the first `rows`
         # leaf rows are evaluated (rows = the smallest tier that holds them; one captured step per tier)
         self.compact_tail = bool(compact_tail)
@@ -177,6 +178,7 @@ class SelfPlayEngine:
             return
         ids = self.first_game_index + (self.games_started + torch.arange(n, device=self.device)) * self.stride
         self.games_started += n
+        self.n_alive += n
         self.rows = self.G                            # new games may sit anywhere
         self.boards[slots] = 0
         self.players[slots] = 1                       # black starts (self_play.py:81)
@@ -206,6 +208,7 @@ class SelfPlayEngine:
         plyi = torch.arange(self.T, device=self.device)[None, :].expand(idx.numel(), -1)
         self.out.append((states[sel], self.hist_pi[idx][sel], z[sel].to(torch.float32), gid[sel], plyi[sel]))
         self.games_finished += int(idx.numel())
+        self.n_alive -= int(idx.numel())
         self.alive[idx] = False
         self.game_id[idx] = -1
         room = max(0, self.games_target - self.games_started)
@@ -213,17 +216,23 @@ class SelfPlayEngine:
 
     # ---- one lockstep move for every live game (self_play.py:91-192)
     def play_move(self):
+        """Every per-move decision is taken on the device with fixed-shape masked operations; the host reads ONE small
+        statistics tensor at the end of the move (positions searched, games finished) and, when games finished, the list of
+        their slots.  Random draws come from the per-game counter streams of csrc/yy_selfplay.hip, so a game's noise and moves
+        depend only on (seed, global game index, ply)."""
         dev, G = self.device, self.G
         if self.compact_tail and self.games_started >= self.games_target:      # the batch is draining
-            n_live = int(self.alive.sum())
-            need = next(t for t in self.tiers if t >= n_live)
+            need = next(t for t in self.tiers if t >= self.n_alive)
             if need < self.rows:
                 self._pack_live_games()
                 self.rows = need
-        ones = torch.ones(G, dtype=torch.int8, device=dev)
+        ones = self._ones
         pending = self.alive.clone()
         searching = torch.zeros(G, dtype=torch.bool, device=dev)
         passes = torch.zeros(G, dtype=torch.int32, device=dev)
+        fin = torch.zeros(G, dtype=torch.bool, device=dev)                     # games that end in this move
+        fin_res = torch.zeros(G, dtype=torch.float64, device=dev)
+        fin_player = self.players.clone()
         for _ in range(2):                                                     # pass handling :103-125
             rp = ones if self.quirks else self.players                         # Q4
             has = engine.valid_mask(self.boards, rp.contiguous(), self.rowcol).bool().any(1)
@@ -233,57 +242,50 @@ class SelfPlayEngine:
             nomove = pending & ~has
             passes += nomove.to(torch.int32)
             over = nomove & (passes >= 2)
-            if bool(over.any()):
-                r = engine.game_ended(self.boards, self.players, self.rowcol)
-                r = torch.where(r == 0, torch.full_like(r, DRAW), r)           # :110-112
-                self._finalize(over, r, self.players)
-                pending &= ~over
+            r = engine.game_ended(self.boards, self.players, self.rowcol)
+            r = torch.where(r == 0, torch.full_like(r, DRAW), r)               # :110-112
+            fin |= over
+            fin_res = torch.where(over, r, fin_res)
+            fin_player = torch.where(over, self.players, fin_player)
+            pending &= ~over
             flip = nomove & ~over
             self.players = torch.where(flip, -self.players, self.players)
         searching &= self.alive
-        if not bool(searching.any()):
-            return 0
         rp = (ones if self.quirks else self.players).contiguous()
-        mask = engine.valid_mask(self.boards, rp, self.rowcol).to(torch.float64)
-        active = searching.to(torch.uint8)
+        mask_u8 = engine.valid_mask(self.boards, rp, self.rowcol)
+        s_u8 = searching.to(torch.uint8)
         noise = None
-        first = searching & (self.ply == 0)                                    # add_noise = (step == 0), :131
-        if self.eps > 0 and bool(first.any()):
-            gam = torch._standard_gamma(torch.full((G, self.A), self.alpha, dtype=torch.float64, device=dev),
-                                        generator=self.gen) * mask
-            noise = torch.where(first[:, None], gam / gam.sum(1, keepdim=True).clamp_min(1e-300), torch.zeros_like(gam))
-            noise = noise.contiguous()
-        self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=active, rows=self.rows)
+        if self.eps > 0:                                                       # add_noise = (step == 0), :131
+            first = (searching & (self.ply == 0)).to(torch.uint8)
+            noise = engine.root_noise(self.seed, self.game_id, self.ply, first, mask_u8, self.alpha)
+        self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=s_u8, rows=self.rows)
         pi = self.ctx.root_policy()                                            # T == 1 distribution, :329
-        # ---- record the example before the move (:140)
-        slot = self.n_ex.clamp_max(self.T - 1)
-        ar = self._ar
-        s_idx = ar[searching]
-        self.hist_state[s_idx, slot[s_idx]] = self.boards[s_idx]
-        self.hist_pi[s_idx, slot[s_idx]] = pi[s_idx].to(torch.float32)
-        self.hist_player[s_idx, slot[s_idx]] = self.players[s_idx]
+        # ---- record the example before the move (:140): fixed-shape scatter, rows of idle games rewrite themselves
+        ar, slot = self._ar, self.n_ex.clamp_max(self.T - 1)
+        self.hist_state[ar, slot] = torch.where(searching[:, None, None], self.boards, self.hist_state[ar, slot])
+        self.hist_pi[ar, slot] = torch.where(searching[:, None], pi.to(torch.float32), self.hist_pi[ar, slot])
+        self.hist_player[ar, slot] = torch.where(searching, self.players, self.hist_player[ar, slot])
         self.n_ex += searching.to(torch.int64)
-        # ---- choose the action (:143-160)
-        probs = pi * mask
-        s = probs.sum(1, keepdim=True)
-        uniform = mask / mask.sum(1, keepdim=True).clamp_min(1.0)
-        probs = torch.where(s > 0, probs / s.clamp_min(1e-300), uniform)
-        best = (pi == pi.max(1, keepdim=True).values).to(torch.float64)
-        dist = torch.where((self.ply < self.thr)[:, None], probs, best)
-        dist = torch.where(searching[:, None], dist, torch.full_like(dist, 1.0 / self.A))
-        action = torch.multinomial(dist.to(torch.float32), 1, generator=self.gen).reshape(-1).to(torch.int32)
-        action = torch.where(searching, action, torch.full_like(action, -1))
+        # ---- choose the action (:143-160) from the game's own stream
+        action = engine.sample_actions(self.seed, self.game_id, self.ply, s_u8, pi, mask_u8, self.thr)
         # ---- make the move (:163); aliased: the search has mutated the game's board (Q2)
         if self.aliased:
             self.boards = torch.where(searching[:, None, None], self.ctx.boards(), self.boards)
-        old_players = self.players.clone()
-        engine.step_(self.boards, self.players, action.contiguous(), self.rowcol)
+        old_players = self.players
+        self.players = self.players.clone()
+        engine.step_(self.boards, self.players, action, self.rowcol)
         self.players = torch.where(searching, self.players, old_players)
         self.ply += searching.to(torch.int32)
         ended = engine.game_ended(self.boards, self.players, self.rowcol)      # :167
-        n_pos = int(searching.sum())
+        done = searching & (ended != 0)
+        fin |= done
+        fin_res = torch.where(done, ended, fin_res)
+        fin_player = torch.where(done, self.players, fin_player)
+        stats = torch.stack([searching.sum(), fin.sum()]).cpu()                # the move's one host read
+        n_pos, n_fin = int(stats[0]), int(stats[1])
         self.positions += n_pos
-        self._finalize(searching & (ended != 0), ended, self.players)
+        if n_fin:
+            self._finalize(fin, fin_res, fin_player)
         return n_pos
 
     def run(self, num_games, progress=None):
@@ -292,12 +294,12 @@ class SelfPlayEngine:
         free = (~self.alive).nonzero(as_tuple=True)[0]
         self._start_games(free[: int(num_games)])
         moves = 0
-        while bool(self.alive.any()):
+        while self.n_alive > 0:
             self.play_move()
             moves += 1
             if progress and moves % 10 == 0:
                 progress(self)
-        self.ctx.status()
+        self.ctx.status()            # per-game search errors are sticky on the device: any failure of any move raises here
         return self.collect()
 
     def collect(self):
