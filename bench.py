@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--oversubscribe", type=int, default=-1,
                     help="N=1 only: a third leg with this many concurrent games (compacted leaf batch ~ whole workgroup "
-                         "rounds); -1 = 4320 for the default workload, 0 = skip")
+                         "rounds); -1 = 4224 for the default workload, 0 = skip")
     ap.add_argument("--oversubscribe-steps", type=int, default=3)
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
@@ -298,25 +298,22 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------- one timed leg
-def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofline):
-    import yinyang_game_alphazero_amd as pkg
-    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, gather_examples
-    dev = torch.device("cuda", torch.cuda.current_device())
-    torch.manual_seed(0)
-    game = pkg.YinYangGame(args.rows, args.cols)
-    net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
-    evaluator = pkg.BatchedEvaluator(net, nn)
-    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games,
-                         board_semantics=args.semantics, reference_quirks=args.quirks,
-                         use_graph=not args.no_graph, seed=1000, device=dev,
-                         first_game_index=rank, game_index_stride=world)
-    stagger_start(eng, 4242 + rank)
+def timed_region(eng, steps, warmup, rank, world, dist, cdev, sims, capacity=None):
+    """The contract's timed region for one engine: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
+    torch.cuda.synchronize() on both sides, the MAX of the elapsed time over ranks, the SUM of positions / evaluator rows
+    over ranks, and the path's single exchange (all-gather of the examples produced in the region) after it.  `eng` needs
+    play_move() -> positions, collect() -> example dict, ctx.status() / ctx.reset_counters(), G (tests drive this with a
+    stand-in engine under gloo, world 2)."""
+    from yinyang_game_alphazero_amd.self_play import gather_examples
+    on_gpu = torch.cuda.is_available()
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(warmup):
         eng.play_move()
@@ -333,8 +330,10 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
     ex = eng.collect()
     # the single exchange of the path: all-gather the examples produced in the timed region
     tg0 = time.perf_counter()
-    ex_all = gather_examples(ex if cdev == dev else {k: v.to(cdev) for k, v in ex.items()})
-    torch.cuda.synchronize()
+    dev0 = ex["states"].device
+    ex_all = gather_examples(ex if cdev == dev0 else {k: v.to(cdev) for k, v in ex.items()}, capacity=capacity)
+    if on_gpu:
+        torch.cuda.synchronize()
     gather_s = time.perf_counter() - tg0
     tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=cdev)
     if dist is not None:
@@ -342,9 +341,27 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dt = float(mx[2])
-    leg = dict(nn=nn, games=games, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), gather_s=gather_s,
-               examples=int(ex_all["states"].shape[0]), sims_total=steps * args.sims * games * world,
-               eval_fraction=counters["evals"] / max(steps * args.sims * games, 1))
+    return dict(games=eng.G, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), gather_s=gather_s,
+                examples=int(ex_all["states"].shape[0]), sims_total=steps * sims * eng.G * world,
+                eval_fraction=counters["evals"] / max(steps * sims * eng.G, 1))
+
+
+def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofline):
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, example_capacity
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(args.rows, args.cols)
+    net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
+    evaluator = pkg.BatchedEvaluator(net, nn)
+    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games,
+                         board_semantics=args.semantics, reference_quirks=args.quirks,
+                         use_graph=not args.no_graph, seed=1000, device=dev,
+                         first_game_index=rank, game_index_stride=world)
+    stagger_start(eng, 4242 + rank)
+    leg = timed_region(eng, steps, warmup, rank, world, dist, cdev, args.sims,
+                       capacity=example_capacity(games * world, world, eng.T))
+    leg["nn"] = nn
     if with_roofline and rank == 0:
         leg["roofline"] = make_roofline(args, eng, games)
     eng.close()
@@ -403,6 +420,28 @@ def leg_summary(leg, note):
             "ms_per_step": leg["dt"] / leg["steps"] * 1e3, "eval_fraction": leg["eval_fraction"], "note": note}
 
 
+def result_line(args, main_leg, world, extra=None, cpub=None):
+    """The ONE JSON line of the contract, from the main leg's totals (already summed / maxed over ranks)."""
+    roof = main_leg.pop("roofline", {"roofline": None})
+    dt = main_leg["dt"]
+    return {
+        "metric": f"self-play positions/sec (+ MCTS node-expansions/sec) at {args.sims} sims, {args.rows}x{args.cols} board",
+        "value": main_leg["positions"] / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.nn,
+        "dtype_note": FP32_GRADE.get(args.nn, "reduced-precision evaluator (the reference evaluates in float32)"),
+        "data": "synthetic",
+        "expansions_per_s": main_leg["evals"] / dt, "simulations_per_s": main_leg["sims_total"] / dt,
+        "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
+                               f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
+                               f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
+                   "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
+                   "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
+        "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
+        **roof, **(extra or {}),
+    }
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -447,37 +486,20 @@ def main():
                 args.secondary_nn, "" if args.secondary_nn in FP32_GRADE else
                 ": REDUCED precision against the reference's float32 (not the headline; parity figures in "
                 "tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi)"))
-        over = args.oversubscribe if args.oversubscribe >= 0 else (4320 if default_workload and args.nn == "f16x3" else 0)
+        over = args.oversubscribe if args.oversubscribe >= 0 else (4224 if default_workload and args.nn == "f16x3" else 0)
         if over > 0:
             leg = run_leg(args, args.nn, over, args.oversubscribe_steps, 1, rank, world, dist, cdev, False)
             extra["oversubscribed"] = leg_summary(leg, f"headline evaluator with {over} concurrent games: the leaves that need "
-                                                       "an evaluation (terminal revisits do not) are compacted into ~4096-row launches = "
-                                                       "8 whole rounds of 2-board workgroups on 256 CUs")
+                                                       "an evaluation (terminal revisits do not: 5-7 % of the simulations) are compacted, so the "
+                                                       "launch carries ~3950-4050 live rows = just under 8 whole rounds of 2-board workgroups "
+                                                       "on 256 CUs")
     cpub = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
         cpub = cpu_baseline(args)
     if dist is not None:
         dist.barrier()
     if rank == 0:
-        roof = main_leg.pop("roofline")
-        dt = main_leg["dt"]
-        line = {
-            "metric": f"self-play positions/sec (+ MCTS node-expansions/sec) at {args.sims} sims, {args.rows}x{args.cols} board",
-            "value": main_leg["positions"] / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.nn,
-            "dtype_note": FP32_GRADE.get(args.nn, "reduced-precision evaluator (the reference evaluates in float32)"),
-            "data": "synthetic",
-            "expansions_per_s": main_leg["evals"] / dt, "simulations_per_s": main_leg["sims_total"] / dt,
-            "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
-                                   f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
-                                   f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
-                       "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
-                       "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
-            "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
-            **roof, **extra,
-        }
-        print(json.dumps(line))
+        print(json.dumps(result_line(args, main_leg, world, extra, cpub)))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -428,6 +428,288 @@ def gen_g3_net800(pool):
     print("wrote", path, len(res), "cases", flush=True)
 
 
+# --------------------------------------------------------------------------- row/column rule (browser JS only)
+def rowcol_boards(R, C, rng, n):
+    """Inputs for the row/column rule: random legal play of the PYTHON reference (which has no such rule: its positions
+    contain full single-coloured lines the JS must react to), iid fills, and boards built to stress the rule: lines with
+    exactly one empty cell whose other cells are one colour / mixed, full single-coloured lines already on the board."""
+    YinYangGame, _, _ = _import_ref()
+    game = YinYangGame(R, C)
+    boards = []
+    while len(boards) < n // 3:
+        boards += [a for a, _ in random_play_positions(game, rng, 6)]
+    boards = boards[: n // 3]
+    while len(boards) < n:
+        kind = len(boards) % 4
+        if kind == 0:
+            arr = adversarial_board(R, C, rng, int(rng.integers(6)))
+        else:
+            arr = np.where(rng.random((R, C)) < rng.uniform(0.2, 0.9), rng.choice([1, -1], size=(R, C)), 0).astype(np.int8)
+            for _ in range(int(rng.integers(1, 3))):
+                colour = int(rng.choice([1, -1]))
+                line = colour * np.ones(C if kind != 2 else R, np.int8)
+                if kind == 3:                                  # mixed line: one stone of the other colour
+                    line[rng.integers(len(line))] = -colour
+                if rng.random() < 0.8:                         # exactly one empty cell
+                    line[rng.integers(len(line))] = 0
+                if kind != 2:
+                    arr[rng.integers(R), :] = line
+                else:
+                    arr[:, rng.integers(C)] = line
+        boards.append(np.asarray(arr, np.int8))
+    return np.stack(boards)
+
+
+def gen_rowcol():
+    """rowcol_<R>x<C>.npz: legal-move masks of the reference's JavaScript game (yin_yang_game.js:187-232, 338-384) for both
+    colours -- the pin of the YY_FLAG_ROWCOL rule path (oracle and HIP)."""
+    import json
+    import subprocess
+    js = os.path.join(REF, "src", "gui", "static", "js", "yin_yang_game.js")
+    sizes = [(6, 6), (8, 8), (12, 12), (4, 4), (3, 3), (5, 7), (2, 9), (1, 6), (7, 1), (16, 12)]
+    sets, inputs = [], []
+    for (R, C) in sizes:
+        rng = np.random.default_rng(4000 + 100 * R + C)
+        b = rowcol_boards(R, C, rng, 2048 if R * C >= 36 else 512)
+        sets.append(b)
+        inputs.append(dict(rows=R, cols=C, boards=b.reshape(len(b), -1).tolist()))
+    res = subprocess.run(["node", os.path.join(OUT, "rowcol_from_js.js"), js], input=json.dumps(inputs).encode(),
+                         stdout=subprocess.PIPE, check=True)
+    for b, r in zip(sets, json.loads(res.stdout)):
+        R, C = r["rows"], r["cols"]
+        path = os.path.join(OUT, f"rowcol_{R}x{C}.npz")
+        p1, m1 = np.asarray(r["p1"], np.uint8), np.asarray(r["m1"], np.uint8)
+        np.savez_compressed(path, boards=b, mask_p1=p1, mask_m1=m1)
+        print("wrote", path, b.shape, "legal density", p1.mean(), m1.mean(), flush=True)
+
+
+# --------------------------------------------------------------------------- arena / select_action (SURVEY 8f-2, a17)
+class _HashNetFromPath:
+    """Stands in for YinYangNeuralNetwork inside the reference's AlphaZero.evaluate: `load_model(path)` picks the hash
+    evaluator from the file NAME (current -> fine, best -> medium), so the reference's own match loop runs unmodified."""
+
+    def __init__(self, game):
+        self.pbits, self.vbits = 10, 11
+
+    def load_model(self, path):
+        self.pbits, self.vbits = (10, 11) if "current" in os.path.basename(path) else (6, 4)
+
+    def predict(self, board):
+        return hash_eval_np(board.get_board(), self.pbits, self.vbits)
+
+
+def _arena_case(args):
+    R, C, sims, copied, num_games = args
+    YinYangGame, YinYangLogic, MCTS = _import_ref()
+    import src.yin_yang.ai.alphazero as az
+    Game = make_copied_game(YinYangGame) if copied else YinYangGame
+    game = Game(R, C)
+    trace = dict(actions=[[]], players=[[]], results=[])
+    orig_next, orig_ended = game.getNextState, game.getGameEnded
+    state = {"depth": 0}
+    orig_search = MCTS.search
+
+    def traced_search(self, board, player, add_exploration_noise=False):
+        state["depth"] += 1
+        try:
+            return orig_search(self, board, player, add_exploration_noise)
+        finally:
+            state["depth"] -= 1
+
+    def traced_next(board, player, action):
+        if state["depth"] == 0:                                # the match loop's own call (alphazero.py:198)
+            trace["actions"][-1].append(int(action))
+            trace["players"][-1].append(int(player))
+        return orig_next(board, player, action)
+
+    def traced_ended(board, player):
+        r = orig_ended(board, player)
+        if state["depth"] == 0 and r != 0:                     # alphazero.py:201-202: the game is over
+            trace["results"].append(float(r))
+            trace["actions"].append([])
+            trace["players"].append([])
+        return r
+
+    game.getNextState, game.getGameEnded = traced_next, traced_ended
+    MCTS.search = traced_search
+    az.YinYangNeuralNetwork = _HashNetFromPath
+    try:
+        a = az.AlphaZero.__new__(az.AlphaZero)
+        a.game, a.num_simulations, a.mcts_threads = game, sims, 1
+        ratio = a.evaluate("current_model.pth.tar", "best_model.pth.tar", num_games=num_games)
+    finally:
+        MCTS.search = orig_search
+    T = max(len(x) for x in trace["actions"]) + 1
+    acts = np.full((num_games, T), -1, np.int32)
+    pls = np.zeros((num_games, T), np.int8)
+    for i in range(num_games):
+        n = len(trace["actions"][i])
+        acts[i, :n], pls[i, :n] = trace["actions"][i], trace["players"][i]
+    res = np.asarray(trace["results"], np.float64)
+    assert len(res) == num_games
+    # the reference's own accounting (alphazero.py:204-216)
+    cur = best = draws = 0
+    for i, r in enumerate(res):
+        first_is_current = (i % 2 == 0)
+        if r == 1:
+            cur, best = (cur + 1, best) if first_is_current else (cur, best + 1)
+        elif r == -1:
+            cur, best = (cur, best + 1) if first_is_current else (cur + 1, best)
+        else:
+            draws += 1
+    assert abs(ratio - cur / num_games) < 1e-12
+    return dict(sims=np.int32(sims), copied=np.uint8(copied), actions=acts, players=pls, results=res,
+                n_moves=np.asarray([len(x) for x in trace["actions"][:num_games]], np.int32),
+                current_wins=np.int32(cur), best_wins=np.int32(best), draws=np.int32(draws), win_ratio=np.float64(ratio))
+
+
+def gen_arena(pool):
+    """arena_<R>x<C>.npz: the reference's AlphaZero.evaluate (alphazero.py:136-226) run unmodified with two hash evaluators
+    ("current" fine, "best" medium): every move of every game, the game results as the loop saw them, and its win / loss / draw
+    accounting -- literal (aliased boards) and with the copied-board game adapter."""
+    for (R, C, sims, n) in ((4, 4, 30, 8), (6, 6, 40, 8), (8, 8, 50, 6)):
+        res = pool.map(_arena_case, [(R, C, sims, copied, n) for copied in (0, 1)], chunksize=1)
+        out = {}
+        for tag, r in zip(("literal", "copied"), res):
+            for k, v in r.items():
+                out[f"{tag}_{k}"] = v
+        path = os.path.join(OUT, f"arena_{R}x{C}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, {t: (int(out[t + "_current_wins"]), int(out[t + "_best_wins"]), int(out[t + "_draws"]),
+                                  out[t + "_n_moves"].tolist()) for t in ("literal", "copied")}, flush=True)
+
+
+def gen_select_action():
+    """select_action.npz: MCTS.select_action (mcts.py:427-479) -- temperature 0 / 1 / 0.5, with and without valid_moves
+    (incl. a mask that removes all visited moves and a wrong-length mask), seeded np.random: the search's pi (hash evaluator)
+    and the action returned."""
+    YinYangGame, YinYangLogic, MCTS = _import_ref()
+    rng = np.random.default_rng(91)
+    rows = []
+    for (R, C, sims) in ((3, 3, 20), (6, 6, 40), (8, 8, 60)):
+        plain = YinYangGame(R, C)
+        Game = make_copied_game(YinYangGame)
+        game = Game(R, C)
+        A = R * C
+        for k in range(24):
+            arr = np.zeros((R, C), np.int8) if k % 3 == 0 else random_play_positions(plain, rng, 1)[0][0]
+            player = -1 if k % 4 == 3 else 1
+            temp = (0, 1.0, 0.5, None)[k % 4]
+            kind = k % 6                      # 0,1: no mask; 2,3: the legal mask; 4: mask removing the searched moves; 5: wrong length
+            lb = YinYangLogic(R, C)
+            lb.board = arr.copy()
+            valid = plain.getValidMoves(lb, player)
+            mcts = MCTS(game, HashEvaluator(6, 4), num_simulations=sims, cpuct=1.0, verbose=0)
+            seed = 700 + k
+            np.random.seed(seed)
+            pi, _ = mcts.search(lb, player)
+            if kind in (0, 1):
+                vm = None
+            elif kind in (2, 3):
+                vm = valid.copy()
+            elif kind == 4:
+                vm = ((pi == 0) & (np.arange(A) % 2 == 0)).astype(np.float64)
+            else:
+                vm = np.ones(A + 3)
+            np.random.seed(seed)
+            lb2 = YinYangLogic(R, C)
+            lb2.board = arr.copy()
+            if temp is not None and temp != 0 and vm is None and pi.sum() > 0 and kind in (0, 1) and valid.sum() == 0:
+                continue
+            action = mcts.select_action(lb2, player, temperature=temp, valid_moves=vm)
+            rows.append(dict(R=R, C=C, sims=sims, board=arr, player=player, temp=-1.0 if temp is None else float(temp),
+                             has_mask=vm is not None, mask=np.zeros(A + 3) if vm is None else np.pad(vm, (0, A + 3 - len(vm))),
+                             mask_len=0 if vm is None else len(vm), seed=seed, pi=pi, action=int(action)))
+    out = {}
+    for (R, C) in ((3, 3), (6, 6), (8, 8)):
+        sel = [r for r in rows if (r["R"], r["C"]) == (R, C)]
+        tag = f"{R}x{C}"
+        out[f"board_{tag}"] = np.stack([r["board"] for r in sel]).astype(np.int8)
+        out[f"pi_{tag}"] = np.stack([r["pi"] for r in sel])
+        out[f"mask_{tag}"] = np.stack([r["mask"] for r in sel])
+        for k, dt in (("player", np.int8), ("temp", np.float64), ("has_mask", np.uint8), ("mask_len", np.int32),
+                      ("seed", np.int32), ("action", np.int32), ("sims", np.int32)):
+            out[f"{k}_{tag}"] = np.asarray([r[k] for r in sel], dt)
+    path = os.path.join(OUT, "select_action.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items() if k.startswith("action")}, flush=True)
+
+
+# --------------------------------------------------------------------------- trainer (SURVEY 8f-3)
+def gen_trainer():
+    """trainer.npz: the reference's AlphaZeroTrainer.train (trainer.py:67-161) for 2 epochs on a 16-channel / 1-block net,
+    batch 8, no augmentation, fixed seeds: the examples, the batch order its DataLoader used, the policy / value loss of
+    every step and every parameter / buffer after the last step."""
+    import tempfile
+    import torch
+    YinYangGame, YinYangLogic, _ = _import_ref()
+    from src.yin_yang.ai.neural_network import YinYangNeuralNetwork
+    from src.yin_yang.ai.trainer import AlphaZeroTrainer
+    torch.set_num_threads(1)
+    R = C = 6
+    game = YinYangGame(R, C)
+    rng = np.random.default_rng(55)
+    boards, pis, zs, examples = [], [], [], []
+    while len(boards) < 44:
+        for arr, pl in random_play_positions(game, rng, 4):
+            lb = YinYangLogic(R, C)
+            lb.board = arr.copy()
+            valid = game.getValidMoves(lb, pl)
+            if valid.sum() == 0:
+                continue                                   # keep every policy row unique: the batch order is recovered from them
+            pi = rng.random(R * C) * valid
+            pi = pi / pi.sum()
+            z = float(rng.choice([1.0, -1.0, 1e-4]))
+            boards.append(arr.astype(np.int8))
+            pis.append(pi)
+            zs.append(z)
+            examples.append((lb, pi, z))
+    boards, pis, zs, examples = boards[:44], pis[:44], zs[:44], examples[:44]
+    with tempfile.TemporaryDirectory() as tmp:
+        trainer = AlphaZeroTrainer(game, model_dir=tmp, lr=0.001, batch_size=8, device=torch.device("cpu"))
+        torch.manual_seed(5)
+        trainer.nnet = YinYangNeuralNetwork(game, num_channels=16, num_res_blocks=1)     # first thing after the seed
+        trainer.optimizer = torch.optim.Adam(trainer.nnet.parameters(), lr=0.001, weight_decay=1e-4)
+        init = {k: v.detach().clone().numpy() for k, v in trainer.nnet.state_dict().items()}
+        log = dict(p=[], v=[], order=[])
+        pol_fn, val_fn = trainer.policy_loss_fn, trainer.value_loss_fn
+        table = np.stack(pis).astype(np.float32)
+
+        def policy_loss(logits, policies):
+            out = pol_fn(logits, policies)
+            log["p"].append(float(out.item()))
+            rows = policies.detach().numpy()
+            match = [np.flatnonzero((table == r).all(1)) for r in rows]
+            assert all(len(m_) == 1 for m_ in match)
+            log["order"].append([int(m_[0]) for m_ in match])
+            return out
+
+        def value_loss(pred, target):
+            out = val_fn(pred, target)
+            log["v"].append(float(out.item()))
+            return out
+
+        trainer.policy_loss_fn, trainer.value_loss_fn = policy_loss, value_loss
+        torch.manual_seed(6)
+        metrics = trainer.train(examples, epochs=2, augment=False)
+        final = {k: v.detach().clone().numpy() for k, v in trainer.nnet.state_dict().items()}
+    steps_per_epoch = (44 + 7) // 8
+    order = np.full((2, steps_per_epoch, 8), -1, np.int32)
+    for s_, idx in enumerate(log["order"]):
+        order[s_ // steps_per_epoch, s_ % steps_per_epoch, : len(idx)] = idx
+    out = dict(boards=np.stack(boards), policies=np.stack(pis), values=np.asarray(zs, np.float64), order=order,
+               policy_loss=np.asarray(log["p"], np.float64), value_loss=np.asarray(log["v"], np.float64),
+               epoch_policy_loss=np.asarray(metrics["policy_loss"]), epoch_value_loss=np.asarray(metrics["value_loss"]),
+               epoch_total_loss=np.asarray(metrics["total_loss"]))
+    for k, v in init.items():
+        out["init/" + k] = v
+    for k, v in final.items():
+        out["final/" + k] = v
+    path = os.path.join(OUT, "trainer.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "steps", len(log["p"]), "losses", metrics["total_loss"], flush=True)
+
+
 # --------------------------------------------------------------------------- G4
 def _episode_case(args):
     R, C, seed, sims, copied, pbits, vbits = args
@@ -617,6 +899,14 @@ def main():
         gen_g3([(3, 3), (4, 4), (6, 6), (8, 8), (12, 12), (5, 7)], pool)
     if "g3net" in only:
         gen_g3_net(pool)
+    if "trainer" in only:
+        gen_trainer()
+    if "arena" in only:
+        gen_arena(pool)
+    if "selact" in only:
+        gen_select_action()
+    if "rowcol" in only:
+        gen_rowcol()
     if "g3net800" in only:
         gen_g3_net800(pool)
     if "g4" in only:

@@ -175,3 +175,124 @@ def test_bench_json_contract(tmp_path):
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] in ("GB/s", "TFLOP/s")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+# ---- arena against the reference's own AlphaZero.evaluate (alphazero.py:136-226), run unmodified with two hash evaluators
+# by tests/golden/make_golden.py (gen_arena): every move of every game, the results the loop saw, its win/loss/draw accounting
+ARENA = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arena_*.npz")))
+
+
+@pytest.mark.parametrize("path", ARENA, ids=[os.path.basename(p) for p in ARENA])
+@pytest.mark.parametrize("tag", ["literal", "copied"])
+def test_arena_equals_reference_evaluate(path, tag):
+    """literal: Arena(literal=True) = the reference's match loop as is (aliased boards mutated by every search, no pass
+    handling, reference scoring).  copied: the default arena (copied boards, passes) under reference_scoring=True against the
+    reference loop driven through the copied-board game adapter.  Same moves (np.argmax of pi: lowest index among the most
+    visited), same players, same game lengths, same getGameEnded values, same current/best/draw counts."""
+    import yinyang_game_alphazero_amd as pkg
+    from hash_eval import hash_eval_torch
+    z = np.load(path)
+    R, C = (int(x) for x in os.path.basename(path)[6:-4].split("x"))
+    game = pkg.YinYangGame(R, C)
+    ev_cur = lambda planes: hash_eval_torch(planes, 10, 11)      # "current" = A
+    ev_best = lambda planes: hash_eval_torch(planes, 6, 4)       # "best" = B
+    sims = int(z[tag + "_sims"])
+    n = z[tag + "_results"].shape[0]
+    arena = pkg.Arena(game, ev_cur, ev_best, num_simulations=sims, literal=(tag == "literal"), reference_scoring=True)
+    res = arena.play(n, record=True)
+    t = arena.transcript
+    assert np.array_equal(t["n_moves"], z[tag + "_n_moves"]), (t["n_moves"], z[tag + "_n_moves"])
+    for i in range(n):
+        k = int(t["n_moves"][i])
+        assert np.array_equal(t["actions"][i, :k], z[tag + "_actions"][i, :k]), (tag, i)
+        assert np.array_equal(t["players"][i, :k], z[tag + "_players"][i, :k]), (tag, i)
+    assert np.array_equal(t["results"], z[tag + "_results"])
+    assert (res["a_wins"], res["b_wins"], res["draws"]) == (int(z[tag + "_current_wins"]), int(z[tag + "_best_wins"]),
+                                                            int(z[tag + "_draws"]))
+
+
+def test_select_action_equals_reference():
+    """MCTS.select_action (mcts.py:427-479) against the reference's recorded actions: temperature 0 (np.argmax), 1, 0.5 and
+    the instance default, with and without valid_moves (the legal mask, a mask that removes every searched move -> arg-max
+    fallback, a wrong-length mask -> ignored), the global numpy stream seeded as the generator seeded it."""
+    import yinyang_game_alphazero_amd as pkg
+    from hash_eval import hash_eval_np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "select_action.npz"))
+
+    class HashNet:
+        def predict(self, board):
+            return hash_eval_np(board.get_board(), 6, 4)
+
+    checked = 0
+    for (R, C) in ((3, 3), (6, 6), (8, 8)):
+        tag = f"{R}x{C}"
+        game = pkg.YinYangGame(R, C)
+        A = R * C
+        for i in range(z["action_" + tag].shape[0]):
+            m = pkg.MCTS(game, HashNet(), num_simulations=int(z["sims_" + tag][i]), board_semantics="copied", verbose=0)
+            board = game.getInitBoard()
+            board.board[...] = z["board_" + tag][i]
+            player = int(z["player_" + tag][i])
+            temp = float(z["temp_" + tag][i])
+            vm = z["mask_" + tag][i][: int(z["mask_len_" + tag][i])] if z["has_mask_" + tag][i] else None
+            np.random.seed(int(z["seed_" + tag][i]))
+            pi, _ = m.search(board, player)
+            assert np.array_equal(pi, z["pi_" + tag][i]), (tag, i)
+            np.random.seed(int(z["seed_" + tag][i]))
+            a = m.select_action(board, player, temperature=None if temp < 0 else temp, valid_moves=vm)
+            assert int(a) == int(z["action_" + tag][i]), (tag, i, temp, vm is not None)
+            m.close()
+            checked += 1
+    assert checked >= 60
+
+
+@pytest.mark.parametrize("graph_step", [False, True], ids=["eager", "hipgraph_step"])
+def test_trainer_steps_equal_reference_trainer_gpu(graph_step):
+    """The same fixture on the GPU (stock PyTorch-ROCm training step, eager and replayed from a hipGraph): per-step losses
+    within 1e-5 relative of the reference's CPU run, parameters within 1e-5 abs after the 12 Adam steps (float32 on another
+    device: summation order differs)."""
+    from test_training_host import _trainer_fixture_run
+    z, log, final, m = _trainer_fixture_run("cuda", graph_step=graph_step)
+    assert log.shape == (12, 2)
+    dl = max(np.abs(log[:, 0] / z["policy_loss"] - 1).max(), np.abs(log[:, 1] - z["value_loss"]).max())
+    worst = max(float(np.abs(v.astype(np.float64) - z["final/" + k].astype(np.float64)).max()) for k, v in final.items()
+                if "num_batches" not in k)
+    print("trainer vs reference (GPU, graph=%s): max loss deviation %.3e, max |dparam| %.3e" % (graph_step, dl, worst))
+    assert dl < 1e-4 and worst < 1e-4
+    assert np.allclose(m["total_loss"], z["epoch_total_loss"], rtol=1e-4)
+
+
+def test_augmentation_and_example_format_on_device_tensors(tmp_path):
+    """f1 on the GPU: the batched 8-fold augmentation on device tensors equals the reference's DataProcessor.augment_sample
+    fixture (exact), and examples written / read back through the .npz formats keep their bits (tensor-native and the
+    reference's object layout)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    from yinyang_game_alphazero_amd import training as T
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment.npz"))
+    for R in (6, 8):
+        boards = torch.from_numpy(z[f"boards_{R}"]).cuda()
+        planes = pkg.engine.encode_planes(boards)
+        pi = torch.from_numpy(z[f"pi_{R}"]).cuda()
+        ap, apol = T.augment_batch(planes, pi)
+        n = boards.shape[0]
+        assert ap.is_cuda and ap.shape[0] == 8 * n
+        # the reference lists the 8 variants per sample; augment_batch stacks variant-major
+        got_p = ap.reshape(8, n, *ap.shape[1:]).permute(1, 0, 2, 3, 4).cpu().numpy()
+        got_pi = apol.reshape(8, n, -1).permute(1, 0, 2).cpu().numpy()
+        assert np.array_equal(got_p, z[f"aug_planes_{R}"]) and np.array_equal(got_pi, z[f"aug_pi_{R}"])
+        # format round trip from device tensors
+        ex = dict(states=boards, policies=pi, values=torch.linspace(-1, 1, n, device="cuda"))
+        path = str(tmp_path / f"ex_{R}.npz")
+        np.savez(path, states=ex["states"].cpu().numpy(), policies=ex["policies"].cpu().numpy().astype(np.float64),
+                 values=ex["values"].cpu().numpy().astype(np.float64))
+        back = T.load_examples(path)
+        assert np.array_equal(np.asarray(back["states"]), boards.cpu().numpy())
+        assert np.allclose(np.asarray(back["policies"]), pi.cpu().numpy()) and np.allclose(np.asarray(back["values"]), ex["values"].cpu().numpy())
+        ref_path = str(tmp_path / f"ref_{R}.npz")
+        T.save_examples_reference_format(ref_path, boards.cpu().numpy(), pi.cpu().numpy(), ex["values"].cpu().numpy())
+        back2 = T.load_examples(ref_path, allow_reference_objects=True)
+        assert np.array_equal(np.asarray(back2["states"]), boards.cpu().numpy())
+        q = T.TrainingDataQueue(max_size=100)
+        q.push_file(ref_path, allow_reference_objects=True)
+        assert len(q) == n

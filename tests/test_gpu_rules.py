@@ -113,3 +113,31 @@ def test_empty_and_errors(E):
         E.valid_mask(torch.zeros((2, 17, 8), dtype=torch.int8, device="cuda"), torch.ones(2, dtype=torch.int8, device="cuda"))
     with pytest.raises(pkg.YYError):
         E.valid_mask(torch.zeros((2, 8, 8), dtype=torch.int8), torch.ones(2, dtype=torch.int8))   # CPU tensors: no fallback
+
+
+ROWCOL = sorted(glob.glob(os.path.join(GOLDEN, "rowcol_*.npz")))
+
+
+@pytest.mark.parametrize("path", ROWCOL, ids=[os.path.basename(p) for p in ROWCOL])
+def test_rowcol_rule_golden_from_reference_javascript(E, path):
+    """YY_FLAG_ROWCOL in the HIP rules kernels against the masks the reference's own JavaScript game produced under node
+    (yin_yang_game.js:187-232, 338-384; generator tests/golden/rowcol_from_js.js).  Bit-exact, both colours; the step
+    kernel places exactly on the legal cells."""
+    import torch
+    z = np.load(path)
+    b = _t(z["boards"])
+    G, R, C = z["boards"].shape
+    p1 = torch.ones(G, dtype=torch.int8, device="cuda")
+    assert np.array_equal(E.valid_mask(b, p1, True).cpu().numpy(), z["mask_p1"])
+    assert np.array_equal(E.valid_mask(b, -p1, True).cpu().numpy(), z["mask_m1"])
+    bl, wh = E.pack_boards(b)
+    k1, k2, _ = E.mask_terminal_bb(bl, wh, R, C, rowcol=True)
+    A = R * C
+    bits = lambda m: ((m.cpu().numpy().astype(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)) \
+        .transpose(1, 0, 2).reshape(G, -1)[:, :A].astype(np.uint8)
+    assert np.array_equal(bits(k1), z["mask_p1"]) and np.array_equal(bits(k2), z["mask_m1"])
+    rng = np.random.default_rng(R * 31 + C)
+    acts = rng.integers(0, A, size=G).astype(np.int32)
+    nb, pl = b.clone(), p1.clone()
+    placed = E.step_(nb, pl, _t(acts), True).cpu().numpy()
+    assert np.array_equal(placed, z["mask_p1"][np.arange(G), acts])

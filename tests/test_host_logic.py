@@ -106,7 +106,7 @@ GATHER_SCRIPT = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import torch, torch.distributed as dist
-from yinyang_game_alphazero_amd.self_play import gather_examples
+from yinyang_game_alphazero_amd.self_play import gather_examples, example_capacity
 dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 n = 3 + 4 * r                      # ragged shards: 3 and 7 examples
@@ -121,6 +121,37 @@ assert out["game_id"].tolist() == [0, 2, 4] + [1 + 2 * i for i in range(7)]
 empty = {k: v[:0] for k, v in ex.items()}
 out2 = gather_examples(empty if r == 0 else ex)         # an empty shard contributes nothing
 assert out2["states"].shape[0] == 7
+# with the agreed capacity the exchange is exactly ONE collective (north_star: a single all-gather); count them
+calls = []
+real = dist.all_gather_into_tensor
+dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+saved = {name: getattr(dist, name) for name in ("all_gather", "all_reduce", "broadcast", "gather", "all_to_all")}
+for name in saved:
+    setattr(dist, name, (lambda nm: (lambda *a, **k: (_ for _ in ()).throw(AssertionError("unexpected collective " + nm))))(name))
+cap = example_capacity(total_games=14, world=w, rows_per_game=1)     # 7 rows per rank
+out3 = gather_examples(ex, capacity=cap)
+assert len(calls) == 1, calls
+for k in out:
+    assert torch.equal(out3[k], out[k]) and out3[k].dtype == ex[k].dtype, k
+try:
+    gather_examples(ex, capacity=2)
+    raise SystemExit("capacity overflow not detected")
+except ValueError:
+    pass
+dist.all_gather_into_tensor = real
+for name, fn in saved.items():
+    setattr(dist, name, fn)
+# publish: rank 0 writes, every rank returns the same complete file
+from yinyang_game_alphazero_amd.self_play import publish_examples_file
+from yinyang_game_alphazero_amd.training import TrainingDataQueue
+path = publish_examples_file(out, sys.argv[2])
+names = [None, None]
+dist.all_gather_object(names, path)
+assert names[0] == names[1] and os.path.exists(path), names
+q = TrainingDataQueue()
+q.push_file(path)
+assert len(q) == 10
+assert not [f for f in os.listdir(sys.argv[2]) if ".tmp" in f]
 dist.destroy_process_group()
 print("rank", r, "ok")
 '''
@@ -131,7 +162,7 @@ def test_gather_examples_gloo_world2(tmp_path):
     script.write_text(GATHER_SCRIPT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29571", str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", str(script), ROOT, str(tmp_path / "data")],
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("ok") == 2
@@ -251,3 +282,66 @@ def test_philox_restatement_known_answers():
     assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+BENCH_FLOW_SCRIPT = r'''
+import json, os, sys, time, types
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import bench
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+
+class Ctx:
+    evals = 0
+    def reset_counters(self): self.evals = 0
+    def status(self): return {"evals": self.evals}
+
+class Eng:                      # stand-in engine: 8 games, 10 sims, rank r is slower and produces fewer positions
+    G = 8
+    def __init__(self): self.ctx, self.n = Ctx(), 0
+    def play_move(self):
+        time.sleep(0.03 * (r + 1))
+        self.ctx.evals += 70 + r
+        self.n += 8 - r
+        return 8 - r
+    def collect(self):
+        n, self.n = self.n, 0
+        return dict(states=torch.full((n, 4, 4), r, dtype=torch.int8), policies=torch.zeros((n, 16)), values=torch.zeros(n),
+                    game_id=torch.arange(n) * w + r, ply=torch.arange(n))
+
+leg = bench.timed_region(Eng(), steps=5, warmup=2, rank=r, world=w, dist=dist, cdev=torch.device("cpu"), sims=10, capacity=64)
+assert leg["positions"] == 5 * (8 + 7), leg                       # SUM over ranks of the TIMED steps only
+assert leg["evals"] == 5 * (70 + 71)
+assert leg["dt"] >= 5 * 0.03 * 2 * 0.98, leg                      # MAX over ranks: the slow rank's time
+assert leg["examples"] == 5 * 15 and leg["sims_total"] == 5 * 10 * 8 * 2
+if r == 0:
+    args = types.SimpleNamespace(sims=10, rows=4, cols=4, steps=5, warmup=2, nn="f16x3", games=8, channels=128, blocks=10,
+                                 semantics="copied", quirks=False, no_graph=False)
+    print("LINE " + json.dumps(bench.result_line(args, dict(leg, nn="f16x3"), w)))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
+    """The N > 1 path of bench.py (warm-up, barrier-bracketed timed region, MAX of the time and SUM of the totals over ranks,
+    the single example exchange, ONE JSON line from rank 0) driven end to end with a stand-in engine on CPU tensors under
+    gloo, world size 2 -- the control flow the driver runs on 2/4/8 GPUs over RCCL."""
+    import json
+    script = tmp_path / "bench_flow.py"
+    script.write_text(BENCH_FLOW_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", str(script), ROOT],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("LINE ")]
+    assert len(lines) == 1
+    line = json.loads(lines[0][5:])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert abs(line["value"] - 75 / (line["ms_per_step"] * 5 / 1e3)) < 1e-6 * line["value"]
+    assert "10 sims" in line["metric"] and "4x4" in line["metric"] and line["vs_baseline"] is None

@@ -51,3 +51,25 @@ def test_hash_eval_matches_generator():
             p0, v0 = O.hash_eval(b, pb, vb)
             p1, v1 = hash_eval_np(b, pb, vb)
             assert np.array_equal(p0, p1) and v0 == v1
+
+
+ROWCOL = sorted(glob.glob(os.path.join(GOLDEN, "rowcol_*.npz")))
+
+
+@pytest.mark.parametrize("path", ROWCOL, ids=[os.path.basename(p) for p in ROWCOL])
+def test_rowcol_rule_against_reference_javascript(path):
+    """The full-row/column rule exists only in the reference's browser game (src/gui/static/js/yin_yang_game.js:187-232,
+    338-384); tests/golden/rowcol_from_js.js ran that class under node and recorded its isValidMove masks for both colours
+    (positions from the Python reference's own random play + boards built to stress the rule).  The oracle's flags=1 path must
+    reproduce them bit for bit -- this pins YY_FLAG_ROWCOL."""
+    z = np.load(path)
+    b = z["boards"]
+    assert np.array_equal(O.valid_mask(b, 1, flags=1), z["mask_p1"])
+    assert np.array_equal(O.valid_mask(b, -1, flags=1), z["mask_m1"])
+    if b.shape[1] > 1 and b.shape[2] > 1:
+        # the rule really bites in the fixture: some masks differ from the rule-less ones
+        assert (O.valid_mask(b, 1, flags=0) != z["mask_p1"]).any()
+
+
+def test_rowcol_fixtures_present():
+    assert len(ROWCOL) >= 8

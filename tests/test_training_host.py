@@ -253,3 +253,42 @@ def test_reference_format_reader_is_restricted(tmp_path):
     with pytest.raises(pickle.UnpicklingError, match="refusing global"):
         load_examples(hostile, allow_reference_objects=True)
     assert not marker.exists()
+
+
+def _trainer_fixture_run(device, graph_step=None):
+    """Our AlphaZeroTrainer driven exactly like the reference run that made tests/golden/trainer.npz: same seed -> same
+    initial 16x1 network, same 44 examples, the batch order the reference's DataLoader used, 2 epochs, batch 8, no
+    augmentation.  Returns (fixture, per-step (policy, value) losses, state_dict, epoch metrics)."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    z = np.load(os.path.join(GOLDEN, "trainer.npz"))
+    game = pkg.YinYangGame(6, 6)
+    torch.manual_seed(5)
+    tr = pkg.AlphaZeroTrainer(game, model_dir=os.path.join(GOLDEN, "..", "..", "gpurun_out", "_trainer_tmp"), lr=0.001,
+                              batch_size=8, device=device, num_channels=16, num_res_blocks=1, graph_step=graph_step)
+    for k, v in tr.nnet.state_dict().items():          # same seed, same module order -> the reference's initial weights
+        assert np.array_equal(v.cpu().numpy(), z["init/" + k]), k
+    ex = dict(states=torch.from_numpy(z["boards"]), policies=torch.from_numpy(z["policies"]).float(),
+              values=torch.from_numpy(z["values"]).float())
+    perms = [torch.from_numpy(np.concatenate([r[r >= 0] for r in z["order"][e]]).astype(np.int64)) for e in range(2)]
+    m = tr.train(ex, epochs=2, augment=False, permutations=perms, log_batches=True)
+    return z, np.asarray(tr.batch_log, np.float64), {k: v.detach().cpu().numpy() for k, v in tr.nnet.state_dict().items()}, m
+
+
+def test_trainer_steps_equal_reference_trainer_cpu():
+    """AlphaZeroTrainer on the CPU against the reference's trainer (trainer.py:67-161; fixture made by make_golden.py
+    gen_trainer): per-step CE(soft targets) and MSE losses, the epoch means and every parameter and BatchNorm buffer after the
+    12 Adam steps.  Same torch ops in the same order on the same device type: tolerance 1e-6 relative (exact in practice)."""
+    import torch
+    torch.set_num_threads(1)
+    z, log, final, m = _trainer_fixture_run("cpu")
+    assert log.shape == (12, 2)
+    assert np.allclose(log[:, 0], z["policy_loss"], rtol=1e-6, atol=0) and np.allclose(log[:, 1], z["value_loss"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(m["policy_loss"], z["epoch_policy_loss"], rtol=1e-6) and np.allclose(m["total_loss"], z["epoch_total_loss"], rtol=1e-6)
+    worst = 0.0
+    for k, v in final.items():
+        want = z["final/" + k]
+        assert v.shape == want.shape, k
+        worst = max(worst, float(np.abs(v.astype(np.float64) - want.astype(np.float64)).max()))
+        assert np.allclose(v, want, rtol=1e-5, atol=1e-7), k
+    print("trainer vs reference (CPU): max |dloss| %.3e, max |dparam| %.3e" % (np.abs(log[:, 0] - z["policy_loss"]).max(), worst))

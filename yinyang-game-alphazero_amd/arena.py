@@ -77,27 +77,45 @@ def _uniform_evaluator(A):
     return ev
 
 
+def _lowest_argmax(pi):
+    """np.argmax(pi) per row: the LOWEST index among the maxima (select_action with temperature 0, mcts.py:471-472)."""
+    A = pi.shape[1]
+    best = pi == pi.max(1, keepdim=True).values
+    idx = torch.arange(A, device=pi.device)[None, :].expand_as(pi)
+    return torch.where(best, idx, torch.full_like(idx, A)).min(1).values.to(torch.int32)
+
+
 class Arena:
     """num_games games between two players on one GPU.  A player is a batched evaluator
     (planes -> policy, value) searched with `num_simulations`, or the string "random" (uniformly random
-    legal moves, RandomPlayer)."""
+    legal moves, RandomPlayer).  Moves of a searching player are np.argmax of the search's pi (lowest index among the most
+    visited moves), exactly the reference's select_action(temperature=0) (alphazero.py:192-195, mcts.py:471-472): a match
+    between two fixed networks is deterministic, as the reference's is."""
 
     def __init__(self, game, player_a, player_b, num_simulations=800, cpuct=1.0, device=None, seed=0,
-                 reference_scoring=False):
+                 reference_scoring=False, literal=False):
         """reference_scoring=True reproduces the reference's attribution literally (alphazero.py:206-218): the value of
-        getGameEnded for the player who would move NEXT is read as "+1 = black won, -1 = white won"."""
+        getGameEnded for the player who would move NEXT is read as "+1 = first player won, -1 = second player won".
+        literal=True reproduces the whole reference match loop (alphazero.py:171-220): the search runs on the game's own
+        board object and mutates it (aliased boards), there is no pass handling -- a side without a move still
+        searches, np.argmax of the uniform pi gives action 0, the illegal placement is ignored and the player flips (Q3) --
+        and the scoring is the reference's."""
         self.game = game
-        self.reference_scoring = bool(reference_scoring)
+        self.literal = bool(literal)
+        self.reference_scoring = bool(reference_scoring) or self.literal
         self.R, self.C = game.getBoardSize()
         self.A = self.R * self.C
         self.pa, self.pb, self.sims, self.cpuct = player_a, player_b, num_simulations, cpuct
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.gen = torch.Generator(device=self.device)
+        self.gen = torch.Generator(device=self.device)      # RandomPlayer moves only
         self.gen.manual_seed(seed)
         self.rowcol = bool(getattr(game, "rowcol_rule", False))
+        self.transcript = None
 
-    def play(self, num_games):
-        """Returns dict(a_wins, b_wins, draws).  Game i: A plays black iff i is even (alphazero.py:177-186)."""
+    def play(self, num_games, record=False):
+        """Returns dict(a_wins, b_wins, draws).  Game i: A plays black iff i is even (alphazero.py:177-186).
+        record=True keeps (actions int32 [G,T], players int8 [G,T], n_moves [G], results float64 [G]) in self.transcript:
+        every call of the match loop's getNextState and the value of getGameEnded that ended each game."""
         G, dev = int(num_games), self.device
         boards = torch.zeros((G, self.R, self.C), dtype=torch.int8, device=dev)
         players = torch.ones(G, dtype=torch.int8, device=dev)
@@ -107,52 +125,80 @@ class Arena:
         ev_b = _uniform_evaluator(self.A) if self.pb == "random" else self.pb
         dense = G <= 1024
         dual = DualEvaluator(ev_a, ev_b, G, self.A, dev, dense=dense)
-        ctx = engine.BatchedMCTS(G, self.R, self.C, max(1, self.sims), cpuct=self.cpuct, rowcol=self.rowcol, device=dev)
-        search = LockstepSearch(ctx, dual, use_graph=dense)     # routed mode: the row sets change every move
-        result = torch.zeros(G, dtype=torch.int8, device=dev)   # +1 black won, -1 white won, 2 draw
-        for _ in range(4 * self.A + 8):
-            if not bool(alive.any()):
-                break
-            mask = engine.valid_mask(boards, players, self.rowcol)
-            has = mask.bool().any(1)
-            # a side without a move passes; when neither side can move the game is over (scored below)
-            players = torch.where(alive & ~has, -players, players).contiguous()
-            mask = engine.valid_mask(boards, players, self.rowcol)
-            has = mask.bool().any(1)
-            movers = alive & has
-            a_to_move = (players == 1) == a_is_black
-            rand_rows = torch.zeros(G, dtype=torch.bool, device=dev)
-            if self.pa == "random":
-                rand_rows |= a_to_move
-            if self.pb == "random":
-                rand_rows |= ~a_to_move
-            action = torch.full((G,), -1, dtype=torch.int32, device=dev)
-            srch = movers & ~rand_rows
-            if bool(srch.any()):
-                dual.assign(a_to_move)
-                search.run(boards, players, self.sims, noise=None, active=srch.to(torch.uint8))
-                pi = ctx.root_policy(temperature_zero=True)          # select_action(temperature=0), :192-195
-                pick = torch.multinomial(torch.where(srch[:, None], pi, torch.full_like(pi, 1.0 / self.A)).float(), 1,
-                                         generator=self.gen).reshape(-1).to(torch.int32)
-                action = torch.where(srch, pick, action)
-            rnd = movers & rand_rows
-            if bool(rnd.any()):
-                m = torch.where(rnd[:, None], mask.float(), torch.full((G, self.A), 1.0, device=dev))
-                pick = torch.multinomial(m, 1, generator=self.gen).reshape(-1).to(torch.int32)
-                action = torch.where(rnd, pick, action)
-            old = players.clone()
-            engine.step_(boards, players, action.contiguous(), self.rowcol)
-            players = torch.where(movers, players, old).contiguous()
-            ended, counts = engine.game_ended(boards, players, self.rowcol, with_counts=True)
-            over = alive & (ended != 0)
-            diff = (counts[:, 0] - counts[:, 1])
-            res = torch.where(diff > 0, 1, torch.where(diff < 0, -1, 2)).to(torch.int8)
-            if self.reference_scoring:
-                res = torch.where(ended == 1, 1, torch.where(ended == -1, -1, 2)).to(torch.int8)
-            result = torch.where(over, res, result)
-            alive &= ~over
-        ctx.status()
-        ctx.close()
+        ctx = engine.BatchedMCTS(G, self.R, self.C, max(1, self.sims), cpuct=self.cpuct, rowcol=self.rowcol, device=dev,
+                                 aliased=self.literal)
+        try:
+            search = LockstepSearch(ctx, dual, use_graph=dense)     # routed mode: the row sets change every move
+            result = torch.zeros(G, dtype=torch.int8, device=dev)   # +1 black won, -1 white won, 2 draw
+            ended_at = torch.zeros(G, dtype=torch.float64, device=dev)
+            T = 4 * self.A + 8
+            rec_a = torch.full((G, T), -1, dtype=torch.int32, device=dev)
+            rec_p = torch.zeros((G, T), dtype=torch.int8, device=dev)
+            n_moves = torch.zeros(G, dtype=torch.int64, device=dev)
+            ar = torch.arange(G, device=dev)
+            for _ in range(T):
+                if not bool(alive.any()):
+                    break
+                if self.literal:
+                    movers = alive.clone()                            # no pass handling: the side to move always "moves"
+                    mask = engine.valid_mask(boards, players, self.rowcol)
+                else:
+                    mask = engine.valid_mask(boards, players, self.rowcol)
+                    has = mask.bool().any(1)
+                    # a side without a move passes; when neither side can move the game is over (scored below)
+                    players = torch.where(alive & ~has, -players, players).contiguous()
+                    if record:     # the reference's loop makes that pass as a move: action 0, ignored, player flips (Q3)
+                        passed = alive & ~has
+                        slot = n_moves.clamp_max(T - 1)
+                        rec_a[ar, slot] = torch.where(passed, torch.zeros_like(rec_a[ar, slot]), rec_a[ar, slot])
+                        rec_p[ar, slot] = torch.where(passed, -players, rec_p[ar, slot])
+                        n_moves += passed.to(torch.int64)
+                    mask = engine.valid_mask(boards, players, self.rowcol)
+                    has = mask.bool().any(1)
+                    movers = alive & has
+                a_to_move = (players == 1) == a_is_black
+                rand_rows = torch.zeros(G, dtype=torch.bool, device=dev)
+                if self.pa == "random":
+                    rand_rows |= a_to_move
+                if self.pb == "random":
+                    rand_rows |= ~a_to_move
+                action = torch.full((G,), -1, dtype=torch.int32, device=dev)
+                srch = movers & ~rand_rows
+                if bool(srch.any()):
+                    dual.assign(a_to_move)
+                    search.run(boards, players, self.sims, noise=None, active=srch.to(torch.uint8))
+                    pi = ctx.root_policy()                               # search() returns the T == 1 distribution (:329)
+                    action = torch.where(srch, _lowest_argmax(pi), action)   # select_action(temperature=0), :471-472
+                    if self.literal:                                     # the search mutated the game's board (Q2)
+                        boards = torch.where(srch[:, None, None], ctx.boards(), boards).contiguous()
+                rnd = movers & rand_rows
+                if bool(rnd.any()):
+                    m = torch.where(rnd[:, None], mask.float(), torch.full((G, self.A), 1.0, device=dev))
+                    pick = torch.multinomial(m, 1, generator=self.gen).reshape(-1).to(torch.int32)
+                    action = torch.where(rnd, pick, action)
+                if record:
+                    slot = n_moves.clamp_max(T - 1)
+                    rec_a[ar, slot] = torch.where(movers, action, rec_a[ar, slot])
+                    rec_p[ar, slot] = torch.where(movers, players, rec_p[ar, slot])
+                    n_moves += movers.to(torch.int64)
+                old = players.clone()
+                engine.step_(boards, players, action.contiguous(), self.rowcol)
+                players = torch.where(movers, players, old).contiguous()
+                ended, counts = engine.game_ended(boards, players, self.rowcol, with_counts=True)
+                over = alive & (ended != 0)
+                diff = (counts[:, 0] - counts[:, 1])
+                res = torch.where(diff > 0, 1, torch.where(diff < 0, -1, 2)).to(torch.int8)
+                if self.reference_scoring:
+                    res = torch.where(ended == 1, 1, torch.where(ended == -1, -1, 2)).to(torch.int8)
+                result = torch.where(over, res, result)
+                ended_at = torch.where(over, ended, ended_at)
+                alive &= ~over
+            ctx.status()
+        finally:
+            ctx.close()
+        if record:
+            self.transcript = dict(actions=rec_a.cpu().numpy(), players=rec_p.cpu().numpy(), n_moves=n_moves.cpu().numpy(),
+                                   results=ended_at.cpu().numpy())
         black_won, white_won = (result == 1), (result == -1)
         a_wins = int(((black_won & a_is_black) | (white_won & ~a_is_black)).sum())
         b_wins = int(((black_won & ~a_is_black) | (white_won & a_is_black)).sum())

@@ -328,29 +328,84 @@ def shard_games(total, rank, world):
 
 
 
-def gather_examples(ex, group=None):
-    """One exchange at iteration end: all_gather of the example counts, then all_gather of the padded
-    (state, pi, z) tensors (RCCL over xGMI on GPUs; gloo on CPU tensors in the tests).  Equivalent of
-    the return_queue.get loop (self_play.py:311-315).  Every rank returns the concatenation in rank
-    order."""
+def example_capacity(total_games, world, rows_per_game):
+    """Upper bound of the examples one rank can produce: its share of the games (shard_games) times the most examples a
+    game can hold.  Every rank computes the same number, so the exchange needs no size negotiation."""
+    return (total_games // world + (1 if total_games % world else 0)) * rows_per_game
+
+
+def gather_examples(ex, group=None, capacity=None):
+    """The ONE exchange of the path (north_star: a single all-gather of the (state, pi, z) examples at iteration end; the
+    reference's return_queue.get loop, self_play.py:311-315).  Every rank packs its examples row-wise into one byte buffer
+    [header: row count | rows: state int8 R*C, pi f32 A, z f32, game id i64, ply i64] and ONE all_gather_into_tensor
+    (RCCL over xGMI on GPUs; gloo on CPU tensors in the tests) delivers all buffers to every rank, which returns the
+    concatenation in rank order.  capacity = rows each rank's buffer holds (`example_capacity`; the same on every rank);
+    without it a second, 8-byte all-gather of the counts sizes the buffers first."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return ex
     world = dist.get_world_size(group)
-    dev = ex["states"].device
-    n = torch.tensor([ex["states"].shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c) for c in counts]
-    n_max = max(counts + [1])
-    out = {}
-    for key, t in ex.items():
-        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        pad[: t.shape[0]] = t
-        buf = torch.empty((world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        dist.all_gather_into_tensor(buf, pad, group=group)
-        out[key] = torch.cat([buf[r * n_max: r * n_max + counts[r]] for r in range(world)])
-    return out
+    keys = sorted(ex)
+    dev = ex[keys[0]].device
+    n = int(ex[keys[0]].shape[0])
+    widths = [int(np.prod(ex[k].shape[1:], dtype=np.int64)) * ex[k].element_size() for k in keys]      # bytes per row and key
+    cols = [ex[k].contiguous().reshape(n, -1).view(torch.uint8) for k in keys] if n else []
+    rb = sum(widths)
+    if capacity is None:
+        mine = torch.tensor([n], dtype=torch.int64, device=dev)
+        every = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        capacity = max(int(every.max()), 1)
+    if n > capacity:
+        raise ValueError(f"gather_examples: {n} examples exceed the agreed capacity {capacity}")
+    HDR = 16
+    buf = torch.zeros(HDR + capacity * rb, dtype=torch.uint8, device=dev)
+    buf[:HDR].view(torch.int64).copy_(torch.tensor([n, rb], dtype=torch.int64))
+    if n:
+        buf[HDR:HDR + n * rb].view(n, rb).copy_(torch.cat(cols, dim=1))
+    out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)                      # <- the single data-path collective
+    out = out.view(world, -1)
+    hdr = out[:, :HDR].contiguous().view(torch.int64).reshape(world, 2).cpu()
+    assert bool((hdr[:, 1] == rb).all()), "ranks disagree on the example row layout"
+    rows = torch.cat([out[r, HDR:HDR + int(hdr[r, 0]) * rb].view(-1, rb) for r in range(world)])
+    res, off = {}, 0
+    for k, w in zip(keys, widths):
+        col = rows[:, off:off + w].contiguous()
+        res[k] = col.view(ex[k].dtype).reshape((rows.shape[0],) + tuple(ex[k].shape[1:]))
+        off += w
+    return res
+
+
+def publish_examples_file(ex, output_dir, reference_format=False):
+    """Rank 0 writes self_play_data_<unix_ts>.npz (self_play.py:374-384) to a temporary name and renames it into place, every
+    rank waits at a barrier until the file is complete, and all ranks return the SAME path (rank 0's, broadcast): a rank that
+    went on to load_data() could otherwise miss the file or open a half-written zip, and a per-rank time stamp could name
+    different files."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    os.makedirs(output_dir, exist_ok=True)
+    filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}.npz")
+    if multi:
+        names = [filename]
+        dist.broadcast_object_list(names, src=0)
+        filename = names[0]
+    if rank == 0:
+        tmp = f"{filename}.{os.getpid()}.tmp.npz"
+        states = ex["states"].cpu().numpy()
+        if reference_format:
+            # `boards` = pickled board objects of the reference's own class, readable by ITS TrainingDataQueue.push_file
+            from .training import save_examples_reference_format
+            save_examples_reference_format(tmp, states, ex["policies"].cpu().numpy(), ex["values"].cpu().numpy())
+        else:
+            np.savez(tmp, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
+                     values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),
+                     ply=ex["ply"].cpu().numpy())
+        os.replace(tmp, filename)
+    if multi:
+        dist.barrier()
+    return filename
 
 
 # =============================================================================== reference API
@@ -473,14 +528,14 @@ class SelfPlayManager:
                              concurrent_games=max(1, min(self.concurrent_games, mine)), cpuct=self.cpuct,
                              dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                              temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
-                             reference_quirks=self.reference_quirks, seed=self.seed * 1000003 + rank,
+                             reference_quirks=self.reference_quirks, seed=1000 + self.seed,   # key of the per-game streams: the same on every rank
                              first_game_index=first, game_index_stride=stride, device=dev)
         t0 = time.perf_counter()
         ex = eng.run(mine) if mine > 0 else eng.collect()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         counters = eng.ctx.status()
-        ex = gather_examples(ex)
+        ex = gather_examples(ex, capacity=example_capacity(total, world, eng.T))
         self.stats = dict(seconds=t1 - t0, positions=eng.positions, games=eng.games_finished, **counters)
         eng.close()
         return ex
@@ -497,18 +552,6 @@ def generate_self_play_data(game, model_path, output_dir, num_games=100, num_wor
     manager = SelfPlayManager(game, model_path, num_workers=num_workers, games_per_worker=games_per_worker,
                               num_simulations=num_simulations, **engine_kwargs)
     ex = manager.generate_games_parallel()
-    import torch.distributed as dist
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}.npz")
-    if rank == 0 and reference_format:
-        # `boards` = pickled board objects of the reference's own class, readable by ITS TrainingDataQueue.push_file
-        from .training import save_examples_reference_format
-        save_examples_reference_format(filename, ex["states"].cpu().numpy(), ex["policies"].cpu().numpy(),
-                                       ex["values"].cpu().numpy())
-    elif rank == 0:
-        states = ex["states"].cpu().numpy()
-        np.savez(filename, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
-                 values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),
-                 ply=ex["ply"].cpu().numpy())
+    filename = publish_examples_file(ex, output_dir, reference_format)
     generate_self_play_data.last_stats = manager.stats
     return filename

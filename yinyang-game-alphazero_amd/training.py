@@ -286,8 +286,12 @@ class AlphaZeroTrainer:
             return engine.encode_planes(states.to(self.device).contiguous())
         return encode_planes_host(states)
 
-    def train(self, examples, epochs=10, augment=True):
-        """trainer.py:67-161.  examples: dict of tensors (or the reference's list of tuples)."""
+    def train(self, examples, epochs=10, augment=True, permutations=None, log_batches=False):
+        """trainer.py:67-161.  examples: dict of tensors (or the reference's list of tuples).
+        permutations: optional list (one int64 index tensor per epoch) replacing the epoch's random order -- the reference
+        shuffles through a DataLoader; a test feeds the order the reference used to compare losses and weights step by step.
+        log_batches: keep (policy_loss, value_loss) of every step in self.batch_log (one host read per step)."""
+        self.batch_log = []
         if not isinstance(examples, dict):
             q = TrainingDataQueue(max_size=max(1, len(examples)))
             q.push_examples(examples)
@@ -310,15 +314,19 @@ class AlphaZeroTrainer:
             model = self._ddp
         self.nnet.train()
         graphed = self.graph_step and dist is None and self.device.type == "cuda" and n >= self.batch_size
-        for _ in range(epochs):
-            perm = torch.randperm(n, device=self.device)
+        for epoch in range(epochs):
+            perm = (torch.randperm(n, device=self.device) if permutations is None
+                    else torch.as_tensor(permutations[epoch], dtype=torch.int64, device=self.device))
             if dist:                                  # the same permutation everywhere, then a disjoint slice per rank
                 dist.broadcast(perm, src=0)
             sums = torch.zeros(4, device=self.device)
             for i in range(0, n, self.batch_size):
                 gidx = perm[i:i + self.batch_size]
                 if graphed and gidx.numel() == self.batch_size:
-                    sums += self._graphed_step(planes, pol, val, gidx) * self.batch_size
+                    out = self._graphed_step(planes, pol, val, gidx)
+                    if log_batches:
+                        self.batch_log.append((float(out[0]), float(out[1])))
+                    sums += out * self.batch_size
                     continue
                 idx = gidx[rank::world]
                 self.optimizer.zero_grad(set_to_none=True)
@@ -335,6 +343,8 @@ class AlphaZeroTrainer:
                 # DDP averages gradients over ranks; weight by this rank's share so the step equals the full-batch mean
                 (loss * (idx.numel() * world / gidx.numel()) if dist else loss).backward()
                 self.optimizer.step()
+                if log_batches:
+                    self.batch_log.append((float(p_loss.detach()), float(v_loss.detach())))
                 sums += torch.stack([p_loss.detach(), v_loss.detach(), loss.detach(), torch.ones((), device=self.device)]) * idx.numel()
             if dist:
                 dist.all_reduce(sums)
