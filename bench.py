@@ -158,7 +158,8 @@ def tower_launcher(eng):
     mode = getattr(ev, "mode", "")
     planes = eng.ctx.planes
     if mode == "f16x3":
-        form = {8: "k_tower_h3 (two boards per workgroup)", 6: "k_tower_h3q<6,4>", 12: "k_tower_h3q<12,1>"}[eng.R]
+        form = {8: "k_tower_h3q<8,2> (two boards per workgroup, wave = output-channel quarter, wave-private weight rings)",
+                6: "k_tower_h3q<6,4>", 12: "k_tower_h3q<12,1>"}[eng.R]
         return (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers),
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
                        "peak = f16 MFMA dense peak / 3",
@@ -388,7 +389,8 @@ def make_roofline(args, eng, games):
     nw = (A + 63) // 64
     bytes_per_launch, shape = algorithmic_bytes(kc, games, A, n_launch, nw)
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    key = dict(games=games, rows=args.rows, cols=args.cols, sims=args.sims, channels=args.channels, blocks=args.blocks)
+    tkey = dict(games=games, rows=args.rows, cols=args.cols, channels=args.channels, blocks=args.blocks)   # the tower launch
+    key = dict(tkey, sims=args.sims, semantics=args.semantics)                                             # the tree kernel
     traffic, src = pmc_traffic("r02_k_mcts_pmc.json", key)
     roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -400,7 +402,7 @@ def make_roofline(args, eng, games):
         _, name, flops, peak = tl
         ach = flops / (tower_ms * 1e-3) / 1e12
         mode = getattr(eng.evaluator, "mode", "")
-        traffic, src = pmc_traffic(f"r02_k_tower_{mode}_hbm_pmc.json", key)
+        traffic, src = pmc_traffic(f"r02_k_tower_{mode}_hbm_pmc.json", tkey)
         out = {"roofline": {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                             "frac": ach / peak, "traffic": traffic, "traffic_source": src, "avg_launch_ms": tower_ms,
                             "algorithmic_flops_per_launch": flops,

@@ -175,6 +175,15 @@ def test_bench_json_contract(tmp_path):
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] in ("GB/s", "TFLOP/s")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["aliased_expansions_per_s"] > 0 and "one per host core" in cb["sample"]
+    # the headline leg evaluates at the reference's precision; the reduced-precision figure is a labelled extra key
+    assert d["dtype"] == "f16x3" and "float32" in d["dtype_note"] and d["config"]["nn_dtype"] == "f16x3"
+    assert "k_tower_h3" in rf["kernel"] and rf["bound"] == "mfma" and "traffic_source" in rf
+    assert "40 sims" in d["metric"] and "8x8" in d["metric"]
+    sec = d["secondary"]
+    assert sec["nn"] == "bf16" and sec["value"] > 0 and "REDUCED" in sec["note"]
+    tree = d["roofline_tree_kernel"]
+    assert tree["bound"] == "hbm" and "traffic_source" in tree and 0 < tree["eval_fraction"] <= 1
 
 
 # ---- arena against the reference's own AlphaZero.evaluate (alphazero.py:136-226), run unmodified with two hash evaluators
@@ -249,17 +258,25 @@ def test_select_action_equals_reference():
 @pytest.mark.parametrize("graph_step", [False, True], ids=["eager", "hipgraph_step"])
 def test_trainer_steps_equal_reference_trainer_gpu(graph_step):
     """The same fixture on the GPU (stock PyTorch-ROCm training step, eager and replayed from a hipGraph): per-step losses
-    within 1e-5 relative of the reference's CPU run, parameters within 1e-5 abs after the 12 Adam steps (float32 on another
-    device: summation order differs)."""
+    within 1e-5 relative of the reference's CPU run, parameters and BatchNorm buffers within 1e-4 abs after the 12 Adam
+    steps (float32 on another device: summation order differs).  One class of parameters is held to a different bound: the
+    bias of a convolution that feeds a BatchNorm has an exactly-zero true gradient (the normalisation removes any constant),
+    so what it receives is rounding noise, which Adam's g / sqrt(v) normalisation turns into steps of +-lr whatever its size;
+    those biases may differ by up to steps * lr and do not influence the network (checked through the losses)."""
     from test_training_host import _trainer_fixture_run
     z, log, final, m = _trainer_fixture_run("cuda", graph_step=graph_step)
     assert log.shape == (12, 2)
     dl = max(np.abs(log[:, 0] / z["policy_loss"] - 1).max(), np.abs(log[:, 1] - z["value_loss"]).max())
-    worst = max(float(np.abs(v.astype(np.float64) - z["final/" + k].astype(np.float64)).max()) for k, v in final.items()
-                if "num_batches" not in k)
-    print("trainer vs reference (GPU, graph=%s): max loss deviation %.3e, max |dparam| %.3e" % (graph_step, dl, worst))
-    assert dl < 1e-4 and worst < 1e-4
-    assert np.allclose(m["total_loss"], z["epoch_total_loss"], rtol=1e-4)
+    dead = lambda k: k.endswith(("conv1.bias", "conv2.bias", "policy_conv.bias", "value_conv.bias"))
+    dev = {k: float(np.abs(v.astype(np.float64) - z["final/" + k].astype(np.float64)).max()) for k, v in final.items()
+           if "num_batches" not in k}
+    worst = max(v for k, v in dev.items() if not dead(k))
+    worst_dead = max(v for k, v in dev.items() if dead(k))
+    print("trainer vs reference (GPU, graph=%s): max loss deviation %.3e, max |dparam| %.3e (zero-gradient conv biases %.3e)"
+          % (graph_step, dl, worst, worst_dead))
+    top = sorted(dev.items(), key=lambda kv: -kv[1])[:6]
+    assert dl < 1e-5 and worst < 1e-4 and worst_dead <= 12 * 0.001 * 2.01, top
+    assert np.allclose(m["total_loss"], z["epoch_total_loss"], rtol=1e-5)
 
 
 def test_augmentation_and_example_format_on_device_tensors(tmp_path):

@@ -401,5 +401,5 @@ def test_split_f16_8x8_kernel_forms_give_identical_bits():
             x = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), ev.h3_b[:ev.h3_layers].contiguous(), ev.h3_layers)
             outs.append((feats.clone(), x.clone()))
     finally:
-        lib().yy_nn_tower_f16x3_set_form8(0)
+        lib().yy_nn_tower_f16x3_set_form8(1)      # the default form
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -32,7 +32,7 @@ for rnd in range(3):
         line = f"round {rnd} {m:7s} G={G}: forward {ms*1e3:8.1f} us"
         if m == "f16x3":
             from yinyang_game_alphazero_amd._lib import lib
-            for form in (1, 0):
+            for form in (0, 1):      # ends on the default form
                 lib().yy_nn_tower_f16x3_set_form8(form)
                 tw = timed(lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers), N)
                 line += f"  [form {form}: tower+headconv {tw*1e3:8.1f} us]"

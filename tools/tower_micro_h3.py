@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Micro-driver for the split-f16 tower kernel (the headline evaluator): G boards, random-init 128x10 net, N launches of
+tower + fused head convs on every row (for rocprofv3 --pmc / --kernel-trace).  python tools/tower_micro_h3.py [G] [N] [form] [R]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+import yinyang_game_alphazero_amd as pkg
+from yinyang_game_alphazero_amd._lib import lib
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+form = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+torch.manual_seed(0)
+net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(R, R)).cuda().eval()
+ev = pkg.BatchedEvaluator(net, "f16x3")
+if form >= 0:
+    lib().yy_nn_tower_f16x3_set_form8(form)
+rng = np.random.default_rng(0)
+planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
+launch = lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(N):
+    launch()
+t1.record(); torch.cuda.synchronize()
+ms = t0.elapsed_time(t1) / N
+cells = R * R
+fl = (2 * 9 * 16 * 128 * cells + 20 * 2 * 9 * 128 * 128 * cells + 2 * 128 * 64 * cells) * G
+print(f"split-f16 tower {R}x{R} G={G}: {ms*1e3:.1f} us/launch, {fl/ms/1e9:.1f} TFLOP/s algorithmic ({3*fl/ms/1e9:.0f} issued)")

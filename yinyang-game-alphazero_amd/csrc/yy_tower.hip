@@ -415,17 +415,23 @@ static int launch_tower(const float *planes, const void *weights, const float *b
         return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
     if (b12) return yy_tower12q_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
     if (b6) return yy_tower6_launch(planes, weights, bias, out, out_heads, G, n_layers, s);
-    static const int dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;   // timing experiments only
-    static const int force_tb = getenv("YY_TOWER_TB") ? atoi(getenv("YY_TOWER_TB")) : 0;     // timing experiments only
     // small batches: 4 boards per workgroup would leave most of the 256 CUs idle; spread the boards over more, lighter
     // workgroups (same results bit for bit)
-    const int tb = force_tb ? force_tb : (G <= YY_TOWER_TB1_MAX_G ? 1 : (G <= YY_TOWER_TB2_MAX_G ? 2 : 4));
+    int tb = G <= YY_TOWER_TB1_MAX_G ? 1 : (G <= YY_TOWER_TB2_MAX_G ? 2 : 4);
+    int dbg = 0;
+#ifdef YY_TOWER_EXPERIMENTS   // timing experiments only (profiles/r01_k_tower_pmc.txt): never compiled into the shipped library
+    static const int env_dbg = getenv("YY_TOWER_DEBUG") ? atoi(getenv("YY_TOWER_DEBUG")) : 0;
+    static const int force_tb = getenv("YY_TOWER_TB") ? atoi(getenv("YY_TOWER_TB")) : 0;
+    dbg = env_dbg;
+    if (force_tb) tb = force_tb;
+#endif
     if (tb == 1 || tb == 2) return yy_tower8q_launch(planes, weights, bias, out, out_heads, G, n_layers, tb, s);
     const dim3 grid((G + TW_TB - 1) / TW_TB), block(256);
     const unsigned char *w = (const unsigned char *)weights;
     unsigned short *o = (unsigned short *)out, *oh = (unsigned short *)out_heads;
     hipStream_t st = (hipStream_t)s;
     switch (dbg) {
+#ifdef YY_TOWER_EXPERIMENTS
         case 1: k_tower<1><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 2: k_tower<2><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 4: k_tower<4><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
@@ -433,6 +439,7 @@ static int launch_tower(const float *planes, const void *weights, const float *b
         case 6: k_tower<6><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 7: k_tower<7><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
         case 8: k_tower<8><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
+#endif
         default: k_tower<0><<<grid, block, 0, st>>>(planes, w, bias, o, oh, G, n_layers); break;
     }
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower: launch failed");

@@ -370,7 +370,9 @@ k_tower_h3(const float *__restrict__ planes, const unsigned char *__restrict__ w
 extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, const float *bias, float *out, float *out_heads,
                                    const int *rows, const int *n_rows, int G, int R, int n_layers, yy_stream_t s);   // yy_tower_h3q.hip
 
-static int g_h3_form8 = 0;   // 8x8 kernel form: 0 = board x cout-half waves (this file), 1 = cout-quarter waves (yy_tower_h3q.hip)
+// 8x8 kernel form: 1 (default) = cout-quarter waves with wave-private weight rings (yy_tower_h3q.hip<8,2,5>: 3.56 ms per
+// 4096-board launch), 0 = board x cout-half waves with the shared ring of this file (3.64 ms; kept as the A/B partner)
+static int g_h3_form8 = 1;
 extern "C" int yy_nn_tower_f16x3_set_form8(int form) {   // A/B measurements (tools/eval_micro.py); same bits either way
     g_h3_form8 = form ? 1 : 0;
     return YY_OK;

@@ -161,9 +161,12 @@ __device__ __forceinline__ void run_layer(f32x16 (&acc)[GEO::CT], unsigned char 
             if (n_chunks - 2 - chunk >= 1) wait_vmcnt<4>();   // chunk+2 may stay in flight
             else wait_vmcnt<0>();
         }
-        if (chunk + 1 < n_chunks || i == 0) {
+        // The chunk layout [ks 4][nt 4][1 KB] and issue_chunk's piece order make wave w load exactly the pieces (nt == w) it
+        // reads itself: the weight ring is wave-private, the counted vmcnt above is all a chunk needs -- no workgroup barrier.
+        // Barriers remain where the waves exchange activations: at the start of a layer and around its epilogue.
+        if (i == 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // chunk+1 landed everywhere; everyone finished chunk-1 (and the epilogue)
+            __builtin_amdgcn_s_barrier();   // the previous layer's epilogue (or the prologue) is visible to every wave
             asm volatile("" ::: "memory");
         }
         if (chunk + 1 < n_chunks && chunk + 3 < n_chunks)

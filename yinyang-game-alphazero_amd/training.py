@@ -263,7 +263,10 @@ class AlphaZeroTrainer:
     """trainer.py:15-212.  Under a multi-rank job (torchrun, one process per GPU) the module is wrapped in
     DistributedDataParallel: every rank holds the same (all-gathered) examples, trains on its 1/world slice of each
     epoch's permutation with batch_size // world samples per step, gradients are all-reduced (RCCL), and rank 0
-    writes the checkpoints -- the global batch and the optimiser schedule match the single-process run."""
+    writes the checkpoints.  The global batch, its order and the optimiser schedule are those of the single-process run and
+    the averaged gradient is the full-batch gradient of the LOSS; BatchNorm, however, normalises with the statistics of each
+    rank's own batch_size // world samples (plain DDP, no SyncBatchNorm), so activations -- and therefore weights -- are
+    close to, not bit-equal to, the single-process run."""
 
     def __init__(self, game, model_dir="models", lr=0.001, batch_size=64, weight_decay=1e-4, device=None,
                  num_channels=128, num_res_blocks=10, graph_step=None):
@@ -331,7 +334,9 @@ class AlphaZeroTrainer:
                 idx = gidx[rank::world]
                 self.optimizer.zero_grad(set_to_none=True)
                 if idx.numel() == 0:                  # ragged tail: contribute a zero gradient, keep the collective in step
+                    self.nnet.eval()                  # a one-sample dummy batch must not touch the BatchNorm running statistics
                     logits, v = model(planes[gidx[:1]])
+                    self.nnet.train()
                     loss = (logits.sum() + v.sum()) * 0.0
                     loss.backward()
                     self.optimizer.step()
