@@ -387,7 +387,8 @@ def make_roofline(args, eng, games):
     k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms = roofline_pass(eng)
     A = args.rows * args.cols
     nw = (A + 63) // 64
-    bytes_per_launch, shape = algorithmic_bytes(kc, games, A, n_launch, nw)
+    # the counters cover the whole move = n_launch + 1 selections (the first one runs before the timed fused steps)
+    bytes_per_launch, shape = algorithmic_bytes(kc, games, A, n_launch + 1, nw)
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     tkey = dict(games=games, rows=args.rows, cols=args.cols, channels=args.channels, blocks=args.blocks)   # the tower launch
     key = dict(tkey, sims=args.sims, semantics=args.semantics)                                             # the tree kernel

@@ -232,6 +232,15 @@ int yy_nn_tower_heads_f16x3(const float *planes, const void *weights, const floa
                             const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
                             int channels, int n_layers, yy_stream_t stream);
 
+/* The same evaluator for 8x8 boards with the weight stream held in REGISTERS (yy_tower_h3r.hip): every wave loads the
+ * fragments of its own output-channel quarter global -> VGPR, nine 16 KB chunks ahead, instead of staging weights through
+ * LDS.  weights / head_w in the wave-major order of network.pack_tower_h3r / pack_heads_h3r; exactly one of out
+ * (float32 [G,8,8,128] tower activations) and out_heads (float32 [G,2,32,64], needs head_w) is non-NULL; rows / n_rows as in
+ * yy_nn_tower_heads_f16x3.  Identical bits to yy_nn_tower_f16x3 / yy_nn_tower_heads_f16x3. */
+int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, const void *head_w, const float *bias,
+                           float *out, float *out_heads, const int32_t *rows, const int32_t *n_rows, int G,
+                           int R, int C, int channels, int n_layers, yy_stream_t stream);
+
 /* 8x8 only: which of the two equivalent workgroup shapes the split-f16 launches use -- 0 = wave = board x output-channel half
  * (yy_tower_h3.hip), 1 = wave = output-channel quarter x both boards with wave-private weight rings (yy_tower_h3q.hip).
  * Identical bits; exported for A/B timing. */

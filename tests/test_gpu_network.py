@@ -403,3 +403,12 @@ def test_split_f16_8x8_kernel_forms_give_identical_bits():
     finally:
         lib().yy_nn_tower_f16x3_set_form8(1)      # the default form
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # third form: the weight stream in registers (csrc/yy_tower_h3r.hip), weights in wave-major order; also with a row gather
+    feats_r = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)
+    x_r = pkg.engine.tower_forward_h3r(planes, ev.h3r_w, ev.h3_b[:ev.h3_layers].contiguous(), ev.h3_layers)
+    assert torch.equal(feats_r, outs[0][0]) and torch.equal(x_r, outs[0][1])
+    flags = torch.from_numpy((rng.random(77) < 0.6).astype(np.uint8)).cuda()
+    rows, n = pkg.engine.compact_rows(flags)
+    fr = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, rows, n)
+    k = int(n)
+    assert torch.equal(fr[:k], outs[0][0][rows[:k].long()])

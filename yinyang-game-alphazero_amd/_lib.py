@@ -32,7 +32,7 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"), os.path.join(CSRC, "yy_tower_h3q.hip"), os.path.join(CSRC, "yy_selfplay.hip"),
+    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"), os.path.join(CSRC, "yy_tower_h3q.hip"), os.path.join(CSRC, "yy_tower_h3r.hip"), os.path.join(CSRC, "yy_selfplay.hip"),
             os.path.join(CSRC, "yy_bitboard.h"), HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
@@ -86,6 +86,7 @@ _SIGS = {
     "yy_nn_head_finish_f32": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "yy_compact_rows": [_vp, C.c_int, _vp, _vp, _vp],
     "yy_nn_tower_f16x3_set_form8": [C.c_int],
+    "yy_nn_tower_f16x3_regs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_selfplay_root_noise": [C.c_uint64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp, _vp],
     "yy_selfplay_sample_actions": [C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "yy_version": [],

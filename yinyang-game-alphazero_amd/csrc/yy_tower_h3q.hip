@@ -369,6 +369,11 @@ extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, con
     if (n_layers + (out_heads ? 1 : 0) > HQ_MAX_LAYERS) return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: too many layers");
     if (R == 6) return launch_hq<6, 4, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
     if (R == 12) return launch_hq<12, 1, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-    if (R == 8) return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (R == 8) {
+        // small batches (arena matches, single-board MCTS.search): one board per workgroup spreads the work over twice as
+        // many CUs while the chip is not full; same bits
+        if (G <= 256) return launch_hq<8, 1, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+        return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    }
     return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: board size");
 }

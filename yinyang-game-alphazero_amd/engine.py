@@ -209,6 +209,39 @@ def tower_heads_forward_h3(planes, weights, bias, n_layers, rows=None, n_rows=No
     return out
 
 
+def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, rows=None, n_rows=None, out=None):
+    """tower_heads_forward_h3 for 8x8 boards with the weight stream in registers (csrc/yy_tower_h3r.hip); weights in the
+    wave-major order of network.pack_tower_h3r / pack_heads_h3r.  Same bits."""
+    G = planes.shape[0]
+    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
+    _need(head_w, torch.int16, (2, 8192), "wave-major split-f16 head weights")
+    _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
+    if rows is not None:
+        _need(rows, torch.int32, (G,), "rows")
+        _need(n_rows, torch.int32, (1,), "n_rows")
+    if out is None:
+        out = torch.empty((G, 2, 2048), dtype=torch.float32, device=planes.device)
+    _need(out, torch.float32, (G, 2, 2048), "out")
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), _p(head_w), _p(bias), None, _p(out), _p(rows), _p(n_rows), G, 8, 8,
+                                           128, n_layers, _stream()))
+    return out
+
+
+def tower_forward_h3r(planes, weights, bias, n_layers):
+    """Tower activations f32 [G,128,8,8] (channels-last memory) from the register-ring kernel (tests)."""
+    G = planes.shape[0]
+    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
+    _need(bias, torch.float32, (n_layers, 128), "tower bias")
+    out = torch.empty((G, 8, 8, 128), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), None, _p(bias), _p(out), None, None, None, G, 8, 8, 128, n_layers,
+                                           _stream()))
+    return out.permute(0, 3, 1, 2)
+
+
 def head_finish_f32(logits, hidden, w2, b2, rows=None, n_rows=None, policy=None, value=None):
     """softmax(logits f32 [G,A]) and tanh(relu(hidden f32 [G,H]) @ w2 + b2) in one HIP pass (csrc k_head_finish_f32);
     with rows / n_rows the result of dense row i lands in row rows[i] of (policy, value) for i < n_rows."""

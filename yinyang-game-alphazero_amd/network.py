@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
+H3R_MIN_ROWS = 256         # above this many rows the 8x8 split-f16 evaluator uses the register-ring kernel (yy_tower_h3r.hip)
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
 INPUT_PLANES = 5
@@ -260,6 +261,20 @@ def pack_heads_h3(net):
     return both.reshape(2, -1).view(torch.int16).contiguous(), bias
 
 
+def pack_tower_h3r(net):
+    """pack_tower_h3 re-ordered "wave-major" for csrc/yy_tower_h3r.hip (weights loaded global -> VGPR by the wave that uses
+    them): chunk = [nt 4][ks 2][part 2][h 2][c 32][j 8] f16, so that the 4 KB of output-channel quarter nt are contiguous."""
+    wq, bq = pack_tower_h3(net)
+    n = wq.shape[0]
+    return wq.view(n, 2, 2, 4, 512).permute(0, 3, 1, 2, 4).contiguous().view(n, 8192), bq
+
+
+def pack_heads_h3r(net):
+    """pack_heads_h3 re-ordered for csrc/yy_tower_h3r.hip: [head 2][ks 8][part 2][h 2][c 32][j 8] f16 (cin = ks*16 + h*8 + j)."""
+    hw, hb = pack_heads_h3(net)                                      # [chunk 2][ks 4][part 2][nt 2][512]
+    return hw.view(2, 4, 2, 2, 512).permute(3, 0, 1, 2, 4).contiguous().view(2, 8192), hb
+
+
 def pack_heads(net):
     """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
     [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
@@ -321,11 +336,18 @@ class BatchedEvaluator:
             self.h3_w = torch.cat([wq, hw]).contiguous().to(self.device)
             self.h3_b = torch.cat([bq, hb]).contiguous().to(self.device)
             self.h3_layers = 1 + 2 * len(net.res_blocks)
+            # 8x8: the same weights in wave-major order for the register-ring kernel (csrc/yy_tower_h3r.hip), the form used
+            # for batches that fill the chip
+            self.h3r_w = self.h3r_hw = None
+            if tuple(net.board_size) == (8, 8):
+                self.h3r_w = pack_tower_h3r(net)[0].to(self.device)
+                self.h3r_hw = pack_heads_h3r(net)[0].to(self.device)
             f32 = lambda t: t.detach().float().contiguous().to(self.device)
             self.pfc_wt, self.pfc_b = f32(net.policy_fc.weight.t()), f32(net.policy_fc.bias)
             self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
             self.fc2_w, self.fc2_b = f32(net.value_fc2.weight.reshape(-1)), f32(net.value_fc2.bias.reshape(1))
             self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
+            self.use_h3r = True
             self.tower = False
             return
         if mode in ("fp32t", "bf16x3"):
@@ -409,7 +431,10 @@ class BatchedEvaluator:
             rows = n = None
             if needs_eval is not None:
                 rows, n = engine.compact_rows(needs_eval)
-            feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, rows, n)   # [G, 2, 32*cells] f32
+            if self.h3r_w is not None and planes.shape[0] > H3R_MIN_ROWS and self.use_h3r:
+                feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, rows, n)
+            else:
+                feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, rows, n)   # [G, 2, 32*cells] f32
             logits = torch.addmm(self.pfc_b, feats[:, 0], self.pfc_wt)                                    # [G, A]
             hidden = torch.addmm(self.vfc1_b, feats[:, 1], self.vfc1_wt)                                  # [G, 256]
             return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n)
