@@ -13,10 +13,9 @@ batch is in the steady state of continuous self-play.  value = positions/s over 
 
 The headline leg runs the evaluator at the REFERENCE's precision: `--nn f16x3` = the split-f16 tower
 (csrc/yy_tower_h3.hip: float32-accurate, identical visit counts to the reference's CPU float32 search on all
-64 golden roots -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 two more
-legs are timed in the same run and reported as extra keys of the same JSON line: `secondary` = the bf16
-tower (reduced precision: NOT the headline) and `oversubscribed` = the headline evaluator with enough
-concurrent games that the compacted leaf batch fills whole workgroup rounds.
+64 golden roots -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 one more
+leg is timed in the same run and reported as an extra key of the same JSON line: `secondary` = the bf16
+tower (reduced precision: NOT the headline); `--oversubscribe G2` adds a leg with G2 concurrent games (`oversubscribed`).
 """
 import argparse
 import ctypes
@@ -56,9 +55,9 @@ def parse():
     ap.add_argument("--secondary-nn", default="bf16", choices=NN_MODES + ["none"],
                     help="N=1 only: a second, shorter leg with this evaluator, reported under `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=3)
-    ap.add_argument("--oversubscribe", type=int, default=-1,
+    ap.add_argument("--oversubscribe", type=int, default=0,
                     help="N=1 only: a third leg with this many concurrent games (compacted leaf batch ~ whole workgroup "
-                         "rounds); -1 = 4224 for the default workload, 0 = skip")
+                         "rounds); 0 (default) = skip: measured neutral, the launch time is proportional to the live rows")
     ap.add_argument("--oversubscribe-steps", type=int, default=3)
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
@@ -158,9 +157,11 @@ def tower_launcher(eng):
     mode = getattr(ev, "mode", "")
     planes = eng.ctx.planes
     if mode == "f16x3":
-        form = {8: "k_tower_h3q<8,2> (two boards per workgroup, wave = output-channel quarter, wave-private weight rings)",
+        form = {8: "k_tower_h3r (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
                 6: "k_tower_h3q<6,4>", 12: "k_tower_h3q<12,1>"}[eng.R]
-        return (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers),
+        regs = eng.R == 8 and ev.h3r_w is not None and G > 256
+        return ((lambda: E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)) if regs else
+                (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)),
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
                        "peak = f16 MFMA dense peak / 3",
                 (2 * 9 * 16 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
@@ -489,7 +490,7 @@ def main():
                 args.secondary_nn, "" if args.secondary_nn in FP32_GRADE else
                 ": REDUCED precision against the reference's float32 (not the headline; parity figures in "
                 "tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi)"))
-        over = args.oversubscribe if args.oversubscribe >= 0 else (4224 if default_workload and args.nn == "f16x3" else 0)
+        over = max(args.oversubscribe, 0)
         if over > 0:
             leg = run_leg(args, args.nn, over, args.oversubscribe_steps, 1, rank, world, dist, cdev, False)
             extra["oversubscribed"] = leg_summary(leg, f"headline evaluator with {over} concurrent games: the leaves that need "

@@ -8,16 +8,19 @@ import yinyang_game_alphazero_amd as pkg
 from yinyang_game_alphazero_amd._lib import lib
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-form = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+form = sys.argv[3] if len(sys.argv) > 3 else "r"     # r = register-ring kernel (8x8 default), 0 / 1 = the LDS-ring forms
 R = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 torch.manual_seed(0)
 net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(R, R)).cuda().eval()
 ev = pkg.BatchedEvaluator(net, "f16x3")
-if form >= 0:
-    lib().yy_nn_tower_f16x3_set_form8(form)
+if form in ("0", "1"):
+    lib().yy_nn_tower_f16x3_set_form8(int(form))
 rng = np.random.default_rng(0)
 planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
-launch = lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
+if form == "r" and R == 8:
+    launch = lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)
+else:
+    launch = lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
 for _ in range(3):
     launch()
 torch.cuda.synchronize()
