@@ -157,9 +157,9 @@ def tower_launcher(eng):
     mode = getattr(ev, "mode", "")
     planes = eng.ctx.planes
     if mode == "f16x3":
-        form = {8: "k_tower_h3r (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
-                6: "k_tower_h3q<6,4>", 12: "k_tower_h3q<12,1>"}[eng.R]
-        regs = eng.R == 8 and ev.h3r_w is not None and G > 256
+        form = {8: "k_tower_h3r<8,2,9> (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
+                6: "k_tower_h3r<6,4,3>", 12: "k_tower_h3r<12,1,3>"}[eng.R]
+        regs = G > ev.h3r_min_rows
         return ((lambda: E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)) if regs else
                 (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)),
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "

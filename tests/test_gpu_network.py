@@ -412,3 +412,29 @@ def test_split_f16_8x8_kernel_forms_give_identical_bits():
     fr = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, rows, n)
     k = int(n)
     assert torch.equal(fr[:k], outs[0][0][rows[:k].long()])
+
+
+@pytest.mark.parametrize("R", [6, 12])
+def test_split_f16_register_ring_kernel_equals_lds_ring_kernel(R):
+    """6x6 / 12x12: csrc/yy_tower_h3r.hip (weight stream in registers, 3-chunk ring) against csrc/yy_tower_h3q.hip (LDS ring):
+    identical bits for the tower activations and for the head features, also through a row gather."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(R, R)
+    net = _randomized_net(pkg, game, 10, 5)
+    ev = pkg.BatchedEvaluator(net, "f16x3")
+    rng = np.random.default_rng(13)
+    G = 37
+    planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
+    n_tower = 9 + 36 * (ev.h3_layers - 1)
+    bias_t = ev.h3_b[:ev.h3_layers].contiguous()
+    f_q = pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
+    x_q = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), bias_t, ev.h3_layers)
+    f_r = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)
+    x_r = pkg.engine.tower_forward_h3r(planes, ev.h3r_w, bias_t, ev.h3_layers)
+    assert torch.equal(f_q, f_r) and torch.equal(x_q, x_r)
+    flags = torch.from_numpy((rng.random(G) < 0.6).astype(np.uint8)).cuda()
+    rows, n = pkg.engine.compact_rows(flags)
+    k = int(n)
+    fr = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, rows, n)
+    assert torch.equal(fr[:k], f_q[rows[:k].long()])

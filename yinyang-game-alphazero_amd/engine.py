@@ -210,10 +210,10 @@ def tower_heads_forward_h3(planes, weights, bias, n_layers, rows=None, n_rows=No
 
 
 def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, rows=None, n_rows=None, out=None):
-    """tower_heads_forward_h3 for 8x8 boards with the weight stream in registers (csrc/yy_tower_h3r.hip); weights in the
-    wave-major order of network.pack_tower_h3r / pack_heads_h3r.  Same bits."""
-    G = planes.shape[0]
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    """tower_heads_forward_h3 with the weight stream in registers (csrc/yy_tower_h3r.hip; boards 6x6 / 8x8 / 12x12); weights in
+    the wave-major order of network.pack_tower_h3r / pack_heads_h3r.  Same bits."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
     _need(head_w, torch.int16, (2, 8192), "wave-major split-f16 head weights")
     _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
@@ -221,23 +221,23 @@ def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, rows=None, 
         _need(rows, torch.int32, (G,), "rows")
         _need(n_rows, torch.int32, (1,), "n_rows")
     if out is None:
-        out = torch.empty((G, 2, 2048), dtype=torch.float32, device=planes.device)
-    _need(out, torch.float32, (G, 2, 2048), "out")
+        out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
+    _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
     with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), _p(head_w), _p(bias), None, _p(out), _p(rows), _p(n_rows), G, 8, 8,
+        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), _p(head_w), _p(bias), None, _p(out), _p(rows), _p(n_rows), G, R, Cc,
                                            128, n_layers, _stream()))
     return out
 
 
 def tower_forward_h3r(planes, weights, bias, n_layers):
-    """Tower activations f32 [G,128,8,8] (channels-last memory) from the register-ring kernel (tests)."""
-    G = planes.shape[0]
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    """Tower activations f32 [G,128,R,R] (channels-last memory) from the register-ring kernel (tests)."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
     _need(bias, torch.float32, (n_layers, 128), "tower bias")
-    out = torch.empty((G, 8, 8, 128), dtype=torch.float32, device=planes.device)
+    out = torch.empty((G, R, Cc, 128), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), None, _p(bias), _p(out), None, None, None, G, 8, 8, 128, n_layers,
+        check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), None, _p(bias), _p(out), None, None, None, G, R, Cc, 128, n_layers,
                                            _stream()))
     return out.permute(0, 3, 1, 2)
 

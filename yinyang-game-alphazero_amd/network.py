@@ -336,12 +336,11 @@ class BatchedEvaluator:
             self.h3_w = torch.cat([wq, hw]).contiguous().to(self.device)
             self.h3_b = torch.cat([bq, hb]).contiguous().to(self.device)
             self.h3_layers = 1 + 2 * len(net.res_blocks)
-            # 8x8: the same weights in wave-major order for the register-ring kernel (csrc/yy_tower_h3r.hip), the form used
-            # for batches that fill the chip
-            self.h3r_w = self.h3r_hw = None
-            if tuple(net.board_size) == (8, 8):
-                self.h3r_w = pack_tower_h3r(net)[0].to(self.device)
-                self.h3r_hw = pack_heads_h3r(net)[0].to(self.device)
+            # the same weights in wave-major order for the register-ring kernel (csrc/yy_tower_h3r.hip), the form used whenever
+            # the batch fills the chip; 8x8 batches of <= H3R_MIN_ROWS boards take the one-board-per-workgroup LDS-ring form
+            self.h3r_w = pack_tower_h3r(net)[0].to(self.device)
+            self.h3r_hw = pack_heads_h3r(net)[0].to(self.device)
+            self.h3r_min_rows = H3R_MIN_ROWS if tuple(net.board_size) == (8, 8) else 0
             f32 = lambda t: t.detach().float().contiguous().to(self.device)
             self.pfc_wt, self.pfc_b = f32(net.policy_fc.weight.t()), f32(net.policy_fc.bias)
             self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
@@ -431,7 +430,7 @@ class BatchedEvaluator:
             rows = n = None
             if needs_eval is not None:
                 rows, n = engine.compact_rows(needs_eval)
-            if self.h3r_w is not None and planes.shape[0] > H3R_MIN_ROWS and self.use_h3r:
+            if planes.shape[0] > self.h3r_min_rows and self.use_h3r:
                 feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, rows, n)
             else:
                 feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, rows, n)   # [G, 2, 32*cells] f32
