@@ -160,8 +160,8 @@ def tower_launcher(eng):
         form = {8: "k_tower_h3r<8,2,9> (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
                 6: "k_tower_h3r<6,4,3>", 12: "k_tower_h3r<12,1,3>"}[eng.R]
         regs = G > ev.h3r_min_rows
-        return ((lambda: E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)) if regs else
-                (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)),
+        return ((lambda: E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps)) if regs else
+                (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)),
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
                        "peak = f16 MFMA dense peak / 3",
                 (2 * 9 * 16 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)

@@ -215,36 +215,36 @@ int yy_nn_tower_bf16x3(const float *planes, const void *weights, const float *bi
 int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2,
                            float *policy, float *value, yy_stream_t stream);
 
-/* The residual tower at FLOAT32 accuracy on the F16 matrix cores ("split-f16"): activations and weights are held as
- * hi = f16(x), lo = f16((x - hi) * 2^11) (22 significant bits), each product is w_hi*x_hi + 2^-11 * (w_hi*x_lo + w_lo*x_hi)
- * on v_mfma_f32_32x32x16_f16 into two f32 accumulators; bias / residual / ReLU in f32.  Agrees with a float64 evaluation
- * to ~4e-7 of scale, like the float32 module itself.  Same I/O as yy_nn_tower_f32; weights = f16 chunks
- * [9 + 36*(n_layers-1)][8192] from network.pack_tower_h3.  Boards 8x8 (two boards per workgroup), 6x6 and 12x12
- * (yy_tower_h3q.hip), 128 channels.  Replaces ai/neural_network.py:94-110 (float32 on the CPU in the reference). */
+/* The residual tower at FLOAT32 accuracy on the F16 matrix cores ("split-f16"; csrc/yy_tower_h3.hip): activations and
+ * weights are held as hi = f16(x), lo = f16(x - hi) (22 significant bits), each product is w_lo*x_hi + w_hi*x_lo + w_hi*x_hi
+ * on v_mfma_f32_32x32x16_f16 into one f32 accumulator; bias / residual / ReLU in f32.  To keep the lo parts in float16's
+ * normal range the weights are stored times 2^weight_exp and the activations (and the bias rows of the tower) live times
+ * 2^act_exp -- exact scalings chosen by network.pack_tower_h3.  Agrees with a float64 evaluation to ~4e-7 of scale, like the
+ * float32 module itself.  Same I/O as yy_nn_tower_f32; weights = f16 chunks [9 + 36*(n_layers-1)][8192].  Boards 6x6, 8x8,
+ * 12x12, 128 channels.  Replaces ai/neural_network.py:94-110 (float32 on the CPU in the reference). */
 int yy_nn_tower_f16x3(const float *planes, const void *weights, const float *bias, float *out, int G,
-                      int R, int C, int channels, int n_layers, yy_stream_t stream);
+                      int R, int C, int channels, int n_layers, int weight_exp, int act_exp,
+                      yy_stream_t stream);
 
-/* Same kernel + the policy_conv / value_conv 1x1 head convolutions, BatchNorm and ReLU (neural_network.py:113, 118):
+/* Same + the policy_conv / value_conv 1x1 head convolutions, BatchNorm and ReLU (neural_network.py:113, 118):
  * out_heads float32 [G,2,32,R*R] = [policy features, value features] in the reference's NCHW flatten order (:114 / :119).
- * weights holds two more chunks and bias one more row (network.pack_heads_h3).  rows / n_rows (device pointers, or both
- * NULL): evaluate planes[rows[i]] for i < *n_rows into out_heads row i; workgroups past *n_rows exit at once. */
+ * weights holds two more chunks (times 2^head_exp) and bias one more, unscaled, row (network.pack_heads_h3).  rows / n_rows
+ * (device pointers, or both NULL): evaluate planes[rows[i]] for i < *n_rows into out_heads row i; workgroups past *n_rows
+ * exit at once. */
 int yy_nn_tower_heads_f16x3(const float *planes, const void *weights, const float *bias, float *out_heads,
                             const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
-                            int channels, int n_layers, yy_stream_t stream);
+                            int channels, int n_layers, int weight_exp, int head_exp, int act_exp,
+                            yy_stream_t stream);
 
-/* The same evaluator for 8x8 boards with the weight stream held in REGISTERS (yy_tower_h3r.hip): every wave loads the
- * fragments of its own output-channel quarter global -> VGPR, nine 16 KB chunks ahead, instead of staging weights through
- * LDS.  weights / head_w in the wave-major order of network.pack_tower_h3r / pack_heads_h3r; exactly one of out
- * (float32 [G,8,8,128] tower activations) and out_heads (float32 [G,2,32,64], needs head_w) is non-NULL; rows / n_rows as in
- * yy_nn_tower_heads_f16x3.  Identical bits to yy_nn_tower_f16x3 / yy_nn_tower_heads_f16x3. */
+/* The same evaluator with the weight stream held in REGISTERS (yy_tower_h3r.hip; the form the engine uses): every wave loads
+ * the fragments of its own output-channel quarter global -> register, up to nine 16 KB chunks ahead, instead of staging
+ * weights through LDS.  weights / head_w in the wave-major order of network.pack_tower_h3r / pack_heads_h3r; exactly one of out
+ * (float32 [G,R,R,128] tower activations) and out_heads (float32 [G,2,32,R*R], needs head_w) is non-NULL; rows / n_rows and the
+ * exponents as above.  Identical bits to yy_nn_tower_f16x3 / yy_nn_tower_heads_f16x3. */
 int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, const void *head_w, const float *bias,
                            float *out, float *out_heads, const int32_t *rows, const int32_t *n_rows, int G,
-                           int R, int C, int channels, int n_layers, yy_stream_t stream);
-
-/* 8x8 only: which of the two equivalent workgroup shapes the split-f16 launches use -- 0 = wave = board x output-channel half
- * (yy_tower_h3.hip), 1 = wave = output-channel quarter x both boards with wave-private weight rings (yy_tower_h3q.hip).
- * Identical bits; exported for A/B timing. */
-int yy_nn_tower_f16x3_set_form8(int form);
+                           int R, int C, int channels, int n_layers, int weight_exp, int head_exp,
+                           int act_exp, yy_stream_t stream);
 
 /* float32 head finish (neural_network.py:115, 120-121, 152): logits float32 [G,A] (policy_fc output, bias added), hidden
  * float32 [G,H] (value_fc1 output, bias added) of dense row i -> policy[g] = softmax(logits[i]),

@@ -31,13 +31,10 @@ for rnd in range(3):
         ms = timed(lambda: ev(planes), N)
         line = f"round {rnd} {m:7s} G={G}: forward {ms*1e3:8.1f} us"
         if m == "f16x3":
-            from yinyang_game_alphazero_amd._lib import lib
-            for form in (0, 1):      # ends on the default form
-                lib().yy_nn_tower_f16x3_set_form8(form)
-                tw = timed(lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers), N)
-                line += f"  [form {form}: tower+headconv {tw*1e3:8.1f} us]"
-            tr = timed(lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers), N)
+            tw = timed(lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps), N)
+            line += f"  [LDS-ring form: tower+headconv {tw*1e3:8.1f} us]"
+            tr = timed(lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps), N)
             line += f"  [register-ring: tower+headconv {tr*1e3:8.1f} us]"
             mc = timed(lambda: ev(planes, needs_eval=flags), N)
-            line += f"  tower+headconv {tw*1e3:8.1f} us ({conv_flops/tw/1e9:.0f} TFLOP/s algorithmic)  compacted(0.937) forward {mc*1e3:8.1f} us"
+            line += f"  ({conv_flops/tr/1e9:.0f} TFLOP/s algorithmic)  compacted(0.937) forward {mc*1e3:8.1f} us"
         print(line, flush=True)

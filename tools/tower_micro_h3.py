@@ -5,22 +5,19 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import yinyang_game_alphazero_amd as pkg
-from yinyang_game_alphazero_amd._lib import lib
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-form = sys.argv[3] if len(sys.argv) > 3 else "r"     # r = register-ring kernel (8x8 default), 0 / 1 = the LDS-ring forms
+form = sys.argv[3] if len(sys.argv) > 3 else "r"     # r = register-ring kernel (the shipped form), q = the LDS-ring kernel
 R = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 torch.manual_seed(0)
 net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(R, R)).cuda().eval()
 ev = pkg.BatchedEvaluator(net, "f16x3")
-if form in ("0", "1"):
-    lib().yy_nn_tower_f16x3_set_form8(int(form))
 rng = np.random.default_rng(0)
 planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
-if form == "r" and R == 8:
-    launch = lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers)
+if form == "r":
+    launch = lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps)
 else:
-    launch = lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers)
+    launch = lambda: pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)
 for _ in range(3):
     launch()
 torch.cuda.synchronize()

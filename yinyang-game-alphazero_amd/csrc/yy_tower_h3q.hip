@@ -3,15 +3,18 @@
 // per workgroup) and 12x12 (config 4, one board per workgroup).  Both are 144 (board, cell) columns = five 32-column MFMA
 // tiles, the last one half padding (the pad columns read the zero row and are never stored: 10 % of the MFMAs).
 //
-// Numerics are those of yy_tower_h3.hip: x = hi + lo * 2^-11 with hi, lo float16; w_hi*x_hi into accumulator 1,
-// w_lo*x_hi + w_hi*x_lo into accumulator 2 (v_mfma_f32_32x32x16_f16), f32 bias / residual / ReLU, re-split.  Same weight
-// chunks (network.pack_tower_h3 / pack_heads_h3), same accumulation order per output element, so a board's bits do not
-// depend on which kernel form or workgroup evaluated it.
+// Numerics are those described in yy_tower_h3.hip: x = hi + lo with hi, lo float16 (weights stored times 2^kw, activations
+// times 2^ka); w_hi*x_hi into one f32 accumulator, w_lo*x_hi + w_hi*x_lo into a second (v_mfma_f32_32x32x16_f16), f32 bias / residual /
+// ReLU, re-split.  Same weight values as yy_tower_h3r.hip (network.pack_tower_h3 / pack_heads_h3; that kernel reads them in
+// wave-major order), same accumulation order per output element, so a board's bits do not depend on which kernel or
+// workgroup evaluated it.
 // Wave w owns output channels [32w, 32w+32) for ALL columns: 5 x {acc1, acc2} accumulators (160 registers) + the f32 residual
 // (80); per k-step 10 activation + 2 weight fragment reads for 15 MFMAs.  LDS: 2 x (144 + 1 zero) rows x 272 B (77 KB) + 4-slot x 16 KB
 // ring + bias = 152.5 KB.  Reference: src/yin_yang/ai/neural_network.py:16-33, 94-119 (float32 on the CPU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/yy_engine.h"
 
@@ -27,8 +30,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define HQ_ROW_BYTES 272
 #define HQ_CHUNK_BYTES 16384
 #define HQ_MAX_LAYERS 22                     // bias rows: 21 tower layers + 1 head row
-#define HQ_LO_SCALE 2048.0f
-#define HQ_LO_INV 0.00048828125f
 
 extern "C" int yy_tower_set_err(int code, const char *msg);
 
@@ -64,9 +65,11 @@ __device__ __forceinline__ void issue_chunk(const unsigned char *wchunk, unsigne
                                          16, 0, 0);
     }
 }
+// two f32 -> packed (hi, hi) and (lo, lo) f16 pairs: hi = f16(x) (round to nearest even), lo = f16(x - hi); x - hi is exact
+// in f32 (written as fma(f32(hi), -1, x): one v_fma_mix_f32 per element)
 __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t &lo) {
     const f16x2 h = __builtin_convertvector(a, f16x2);
-    const f32x2 r = (a - __builtin_convertvector(h, f32x2)) * HQ_LO_SCALE;
+    const f32x2 r = {__builtin_fmaf((float)h.x, -1.0f, a.x), __builtin_fmaf((float)h.y, -1.0f, a.y)};
     const f16x2 l = __builtin_convertvector(r, f16x2);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
@@ -74,7 +77,7 @@ __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t
 __device__ __forceinline__ f32x2 join_pair(const uint32_t hi, const uint32_t lo) {
     const f32x2 h = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
     const f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
-    return (f32x2){__builtin_fmaf(l.x, HQ_LO_INV, h.x), __builtin_fmaf(l.y, HQ_LO_INV, h.y)};
+    return h + l;
 }
 // Ring protocol of one chunk.  The chunk layout [ks 2][part 2][nt 4][1 KB] and the piece order of issue_chunk make wave w
 // load exactly the four 1 KB pieces (nt == w) that wave w itself reads: the weight ring is WAVE-PRIVATE, so a chunk costs
@@ -118,6 +121,7 @@ __device__ __forceinline__ void load_frags(Frags<GEO::CT> &f, const unsigned cha
     f.wh = __builtin_bit_cast(f16x8, *(const u32x4 *)wslot);
     f.wl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wslot + 4096));
 }
+// acc1 += w_hi * x_hi ;  acc2 += w_lo * x_hi + w_hi * x_lo   (same order as yy_tower_h3r.hip; why two accumulators: there)
 template <int CT, bool ZERO>
 __device__ __forceinline__ void mma_ct(f32x16 (&acc1)[CT], f32x16 (&acc2)[CT], const Frags<CT> &f) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -206,7 +210,8 @@ template <int R_, int TB_, int NSLOT_>
 __global__ void __launch_bounds__(256, 1)
 k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
             float *__restrict__ out, float *__restrict__ out_heads, const int *__restrict__ rows,
-            const int *__restrict__ n_rows, int G, int n_layers) {
+            const int *__restrict__ n_rows, int G, int n_layers, float in_scale, float acc_scale, float head_scale,
+            float out_scale) {
     using GEO = Geo<R_, TB_, NSLOT_>;
     constexpr int CT = GEO::CT, CELLS = GEO::CELLS, NCOL = GEO::NCOL, TB = GEO::TB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GEO::LDS_BYTES];
@@ -228,7 +233,7 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
         const int src = live ? (rows ? rows[gb] : gb) : 0;
         float p[6];
 #pragma unroll
-        for (int k = 0; k < 5; k++) p[k] = live ? planes[((size_t)src * 5 + k) * CELLS + cell] : 0.0f;
+        for (int k = 0; k < 5; k++) p[k] = live ? planes[((size_t)src * 5 + k) * CELLS + cell] * in_scale : 0.0f;
         p[5] = 0.0f;
         uint32_t hi[3], lo[3];
 #pragma unroll
@@ -260,34 +265,38 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // every wave has finished reading this layer's input
         asm volatile("" ::: "memory");
-        const bool conv2 = (L >= 2) && ((L & 1) == 0);
-        const bool keep = (L == 0) || conv2;
-        f32x4 bq[4];
+        auto epilogue = [&](auto conv2_tag, auto keep_tag) {
+            constexpr bool conv2 = decltype(conv2_tag)::value, keep = decltype(keep_tag)::value;   // resolved once per layer
+            f32x4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *(const f32x4 *)(lds + GEO::BIAS_OFF + (L * HQ_CH + nh * 32 + 8 * q + 4 * h) * 4);
+            for (int q = 0; q < 4; q++) bq[q] = *(const f32x4 *)(lds + GEO::BIAS_OFF + (L * HQ_CH + nh * 32 + 8 * q + 4 * h) * 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int co = nh * 32 + 8 * q + 4 * h;       // this lane's 4 couts
-            const f32x4 b = bq[q];
+            for (int q = 0; q < 4; q++) {
+                const int co = nh * 32 + 8 * q + 4 * h;       // this lane's 4 couts
+                const f32x4 b = bq[q];
 #pragma unroll
-            for (int tt = 0; tt < CT; tt++) {
-                f32x4 v;
+                for (int tt = 0; tt < CT; tt++) {
+                    f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(acc2[tt][4 * q + i], HQ_LO_INV, acc1[tt][4 * q + i]) + b[i];
-                if (conv2) v += res[tt][q];
+                    for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(acc1[tt][4 * q + i] + acc2[tt][4 * q + i], acc_scale, b[i]);
+                    if (conv2) v += res[tt][q];
 #pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.0f);
-                if (keep) res[tt][q] = v;
-                uint32_t h01, l01, h23, l23;
-                split_pair((f32x2){v[0], v[1]}, h01, l01);
-                split_pair((f32x2){v[2], v[3]}, h23, l23);
-                const int col = tt * 32 + c;
-                if (col < NCOL) {
-                    *(u32x2 *)(lds + col * HQ_ROW_BYTES + co * 2) = (u32x2){h01, h23};
-                    *(u32x2 *)(lds + GEO::PART_BYTES + col * HQ_ROW_BYTES + co * 2) = (u32x2){l01, l23};
+                    for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.0f);
+                    if (keep) res[tt][q] = v;
+                    uint32_t h01, l01, h23, l23;
+                    split_pair((f32x2){v[0], v[1]}, h01, l01);
+                    split_pair((f32x2){v[2], v[3]}, h23, l23);
+                    const int col = tt * 32 + c;
+                    if (NCOL % 32 == 0 || col < NCOL) {
+                        *(u32x2 *)(lds + col * HQ_ROW_BYTES + co * 2) = (u32x2){h01, h23};
+                        *(u32x2 *)(lds + GEO::PART_BYTES + col * HQ_ROW_BYTES + co * 2) = (u32x2){l01, l23};
+                    }
                 }
             }
-        }
+        };
+        if (L == 0) epilogue(std::false_type{}, std::true_type{});                    // stem: a block input
+        else if ((L & 1) == 0) epilogue(std::true_type{}, std::true_type{});          // second conv of a block: + skip, keep
+        else epilogue(std::false_type{}, std::false_type{});
     }
     if (out_heads) {
         // 1x1 head convs: two chunks [ks 4][part 2][nt 2][h 2][c 32][j 8]; wave w: head (w & 1), column tiles
@@ -331,7 +340,7 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
                         float *o = out_heads + (((size_t)gb * 2 + head) * 32 + 8 * q + 4 * h) * CELLS + cell;
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            o[i * CELLS] = fmaxf(__builtin_fmaf(h2[t][4 * q + i], HQ_LO_INV, h1[t][4 * q + i]) + b[i], 0.0f);
+                            o[i * CELLS] = fmaxf(__builtin_fmaf(h1[t][4 * q + i] + h2[t][4 * q + i], head_scale, b[i]), 0.0f);
                     }
                 }
             }
@@ -347,7 +356,7 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
             const u32x2 ph = *(const u32x2 *)(lds + col * HQ_ROW_BYTES + ch4 * 8);
             const u32x2 pl = *(const u32x2 *)(lds + GEO::PART_BYTES + col * HQ_ROW_BYTES + ch4 * 8);
             const f32x2 v01 = join_pair(ph.x, pl.x), v23 = join_pair(ph.y, pl.y);
-            *(f32x4 *)(out + ((size_t)g0 * CELLS + col) * HQ_CH + ch4 * 4) = (f32x4){v01.x, v01.y, v23.x, v23.y};
+            *(f32x4 *)(out + ((size_t)g0 * CELLS + col) * HQ_CH + ch4 * 4) = (f32x4){v01.x, v01.y, v23.x, v23.y} * out_scale;
         }
     }
 }
@@ -356,24 +365,24 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
 template <int R_, int TB_, int NSLOT_>
 static int launch_hq(const float *planes, const void *weights, const float *bias, float *out, float *out_heads, const int *rows,
-                     const int *n_rows, int G, int n_layers, yy_stream_t s) {
+                     const int *n_rows, int G, int n_layers, const float *sc, yy_stream_t s) {
     thq::k_tower_h3q<R_, TB_, NSLOT_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
-        planes, (const unsigned char *)weights, bias, out, out_heads, rows, n_rows, G, n_layers);
+        planes, (const unsigned char *)weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc[0], sc[1], sc[2], sc[3]);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3: launch failed");
     return YY_OK;
 }
 
 // called by yy_tower_h3.hip: R = 6 (four boards per workgroup), 12 (one board per workgroup), 8 (two boards per workgroup)
 extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, const float *bias, float *out, float *out_heads,
-                                   const int *rows, const int *n_rows, int G, int R, int n_layers, yy_stream_t s) {
+                                   const int *rows, const int *n_rows, int G, int R, int n_layers, const float *sc, yy_stream_t s) {
     if (n_layers + (out_heads ? 1 : 0) > HQ_MAX_LAYERS) return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: too many layers");
-    if (R == 6) return launch_hq<6, 4, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-    if (R == 12) return launch_hq<12, 1, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (R == 6) return launch_hq<6, 4, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
+    if (R == 12) return launch_hq<12, 1, 4>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     if (R == 8) {
         // small batches (arena matches, single-board MCTS.search): one board per workgroup spreads the work over twice as
         // many CUs while the chip is not full; same bits
-        if (G <= 256) return launch_hq<8, 1, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-        return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+        if (G <= 256) return launch_hq<8, 1, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
+        return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     }
     return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: board size");
 }

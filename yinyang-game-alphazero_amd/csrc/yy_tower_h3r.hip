@@ -13,15 +13,21 @@
 // XCD's 4 MB L2, every round of workgroups re-streams it from the Infinity Cache, and the workgroups of an XCD run in step,
 // so every chunk exposed that latency to the 3-deep LDS ring.  Measured on 4096 boards: 3.44 ms against 3.65 ms (cout-quarter
 // form with wave-private LDS rings) and 3.72 ms (board x cout-half form, shared LDS ring) in the same process.
-// LDS now holds only the activations ({hi, lo} x (columns + a zero row) x 272 B) and the bias table.
+// LDS now holds only the activations ({hi, lo} x (columns + a zero row) x 272 B), the bias table and (8x8) the f32 residual.
 //
-// Numerics, accumulation order and output bits are those of the other two forms (tested equal).  Weight layout ("wave-major",
+// Numerics (yy_tower_h3.hip): x = hi + lo with hi = f16(x), lo = f16(x - hi); weights are stored times 2^kw and activations (and
+// the bias table) live times 2^ka so that the lo parts stay in float16's normal range; per tile one f32 accumulator takes
+// w_hi*x_hi and a second one w_lo*x_hi + w_hi*x_lo; the epilogue is fma(acc1 + acc2, 2^-kw, bias).  Output bits equal
+// yy_tower_h3q.hip's (tested).  Weight layout ("wave-major",
 // network.pack_tower_h3r): chunk = one tap x 32 input channels = [nt 4][ks 2][part 2][h 2][c 32][j 8] f16 (4 KB per wave,
 // contiguous), cin = quarter*32 + ks*16 + h*8 + j, cout = nt*32 + c; stem: one chunk per tap (ks 0 only carries data), every
 // other layer 36 (tap-major, then quarter); heads: [head 2][ks 8][part 2][h 2][c 32][j 8] (cin = ks*16 + h*8 + j).
 // Reference: src/yin_yang/ai/neural_network.py:16-33, 94-119 (float32 on the CPU).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/yy_engine.h"
 
@@ -37,8 +43,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define HR_ROW_BYTES 272
 #define HR_CHUNK_BYTES 16384
 #define HR_MAX_LAYERS 22
-#define HR_LO_SCALE 2048.0f
-#define HR_LO_INV 0.00048828125f
 
 extern "C" int yy_tower_set_err(int code, const char *msg);
 
@@ -49,14 +53,19 @@ template <int R_, int TB_, int D_, int NV_> struct Geo {
     static constexpr int PART_BYTES = (NCOL + 1) * HR_ROW_BYTES;    // one part (hi or lo) of every column + its zero row
     static constexpr int ZERO_OFF = NCOL * HR_ROW_BYTES;
     static constexpr int BIAS_OFF = 2 * PART_BYTES;
-    static constexpr int LDS_BYTES = BIAS_OFF + HR_MAX_LAYERS * HR_CH * 4;
+    // the f32 residual of a block input lives in LDS where it fits (8x8: 4 waves x 16 KB, lane-private 16-B slots, so the
+    // 64 registers it would occupy across the MFMA loop are free); 6x6 / 12x12 keep it in registers
+    static constexpr bool RES_LDS = (CT == 4);
+    static constexpr int RES_OFF = BIAS_OFF + HR_MAX_LAYERS * HR_CH * 4;
+    static constexpr int LDS_BYTES = RES_OFF + (RES_LDS ? 4 * 16 * 1024 : 0);
     static_assert(36 % D_ == 0 && 9 % D_ == 0, "ring depth must divide the chunks of a layer (36) and of the stem (9)");
     static_assert(PART_BYTES + 256 < 65536 && LDS_BYTES <= 163840, "LDS layout");
 };
 
+// two f32 -> packed (hi, hi) and (lo, lo) f16 pairs: hi = f16(x) (round to nearest even), lo = f16(x - hi); x - hi is exact in f32
 __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t &lo) {
     const f16x2 h = __builtin_convertvector(a, f16x2);
-    const f32x2 r = (a - __builtin_convertvector(h, f32x2)) * HR_LO_SCALE;
+    const f32x2 r = a - __builtin_convertvector(h, f32x2);
     const f16x2 l = __builtin_convertvector(r, f16x2);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
@@ -64,7 +73,7 @@ __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t
 __device__ __forceinline__ f32x2 join_pair(const uint32_t hi, const uint32_t lo) {
     const f32x2 h = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2);
     const f32x2 l = __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
-    return (f32x2){__builtin_fmaf(l.x, HR_LO_INV, h.x), __builtin_fmaf(l.y, HR_LO_INV, h.y)};
+    return h + l;
 }
 
 // this wave's fragments of one weight chunk: [ks 2]{hi, lo}, 16 registers
@@ -107,7 +116,9 @@ __device__ __forceinline__ void load_x(XFrags<GEO::CT> &f, const unsigned char *
         f.l[tt] = __builtin_bit_cast(f16x8, *(const u32x4 *)(lds + cb[tt] + GEO::PART_BYTES + quarter * 64 + ks * 32));
     }
 }
-// acc1 += w_hi * x_hi ;  acc2 += w_lo * x_hi + w_hi * x_lo   (acc2 carries the 2^11 scale of the lo parts)
+// acc1 += w_hi * x_hi ;  acc2 += w_lo * x_hi + w_hi * x_lo.  Two accumulators because every MFMA rounds its accumulator once:
+// the large sum is rounded once per k-step (as in an f32 dot product) and the 2^-11-times-smaller corrections round among
+// themselves; one shared accumulator measured 1.7x the error (three roundings of the large sum per k-step).
 template <int CT, bool ZERO>
 __device__ __forceinline__ void mma(f32x16 (&acc1)[CT], f32x16 (&acc2)[CT], const f16x8 wh, const f16x8 wl, const XFrags<CT> &x) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -203,7 +214,8 @@ template <int R_, int TB_, int D_, int NV_>
 __global__ void __launch_bounds__(256, 1)
 k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const unsigned char *__restrict__ head_w,
             const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ out_heads,
-            const int *__restrict__ rows, const int *__restrict__ n_rows, int G, int n_layers) {
+            const int *__restrict__ rows, const int *__restrict__ n_rows, int G, int n_layers, float in_scale,
+            float acc_scale, float head_scale, float out_scale) {
     using GEO = Geo<R_, TB_, D_, NV_>;
     constexpr int CT = GEO::CT, CELLS = GEO::CELLS, NCOL = GEO::NCOL, TB = GEO::TB, D = GEO::D;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GEO::LDS_BYTES];
@@ -231,7 +243,7 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
         const int src = live ? (rows ? rows[gb] : gb) : 0;
         float p[6];
 #pragma unroll
-        for (int k = 0; k < 5; k++) p[k] = live ? planes[((size_t)src * 5 + k) * CELLS + cell] : 0.0f;
+        for (int k = 0; k < 5; k++) p[k] = live ? planes[((size_t)src * 5 + k) * CELLS + cell] * in_scale : 0.0f;
         p[5] = 0.0f;
         uint32_t hi[3], lo[3];
 #pragma unroll
@@ -245,13 +257,23 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
     LaneGeo<GEO> geo;
     make_lane_geo<GEO>(geo, c, h);
-    f32x4 res[CT][4];      // residual x of this wave's 32 couts, f32
+    f32x4 res[CT][4];      // residual x of this wave's 32 couts, f32 (registers: only when !GEO::RES_LDS)
+    unsigned char *res_lds = lds + GEO::RES_OFF + (wave * 16) * 1024 + lane * 16;   // slot (q * CT + tt) * 1 KB, lane-private
     int chunk = 0;
-    // bias (+ residual) + ReLU in f32, split again, back to LDS; `keep`: the output is a block input x, kept for the skip
-    auto epilogue = [&](const int L, f32x16 (&acc1)[CT], f32x16 (&acc2)[CT], const bool conv2, const bool keep) {
+    // (acc1 + acc2) * 2^-kw + bias (+ residual) + ReLU in f32, split again, back to LDS (activations, bias table and residual
+    // live in the 2^ka-scaled domain); KEEP: the output is a block input x, kept for the skip; resolved once per layer
+    auto epilogue = [&](const int L, f32x16 (&acc1)[CT], f32x16 (&acc2)[CT], auto conv2_tag, auto keep_tag) {
+        constexpr bool CONV2 = decltype(conv2_tag)::value, KEEP = decltype(keep_tag)::value;
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) bq[q] = *(const f32x4 *)(lds + GEO::BIAS_OFF + (L * HR_CH + nh * 32 + 8 * q + 4 * h) * 4);
+        f32x4 rl[GEO::RES_LDS && CONV2 ? CT : 1][4];
+        if (GEO::RES_LDS && CONV2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int tt = 0; tt < CT; tt++) rl[tt][q] = *(const f32x4 *)(res_lds + (q * CT + tt) * 1024);
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int co = nh * 32 + 8 * q + 4 * h;       // this lane's 4 couts
@@ -260,11 +282,14 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
             for (int tt = 0; tt < CT; tt++) {
                 f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(acc2[tt][4 * q + i], HR_LO_INV, acc1[tt][4 * q + i]) + b[i];
-                if (conv2) v += res[tt][q];
+                for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(acc1[tt][4 * q + i] + acc2[tt][4 * q + i], acc_scale, b[i]);
+                if (CONV2) v += GEO::RES_LDS ? rl[GEO::RES_LDS && CONV2 ? tt : 0][q] : res[tt][q];
 #pragma unroll
                 for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.0f);
-                if (keep) res[tt][q] = v;
+                if (KEEP) {
+                    if (GEO::RES_LDS) *(f32x4 *)(res_lds + (q * CT + tt) * 1024) = v;
+                    else res[tt][q] = v;
+                }
                 uint32_t h01, l01, h23, l23;
                 split_pair((f32x2){v[0], v[1]}, h01, l01);
                 split_pair((f32x2){v[2], v[3]}, h23, l23);
@@ -281,15 +306,15 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
         __syncthreads();                                   // the prologue's LDS writes are visible
         run_layer<GEO, true>(acc1, acc2, W, lds, weights, voff, chunk, n_tower, geo);
         __syncthreads();                                   // every wave has finished reading the input
-        epilogue(0, acc1, acc2, false, true);
+        epilogue(0, acc1, acc2, std::false_type{}, std::true_type{});
     }
     for (int L = 1; L < n_layers; L++) {
         f32x16 acc1[CT], acc2[CT];
         __syncthreads();                                   // the previous layer's epilogue is visible
         run_layer<GEO, false>(acc1, acc2, W, lds, weights, voff, chunk, n_tower, geo);
         __syncthreads();                                   // every wave has finished reading this layer's input
-        const bool conv2 = (L & 1) == 0;
-        epilogue(L, acc1, acc2, conv2, conv2);
+        if ((L & 1) == 0) epilogue(L, acc1, acc2, std::true_type{}, std::true_type{});      // second conv of a block: + skip, keep
+        else epilogue(L, acc1, acc2, std::false_type{}, std::false_type{});
     }
     __syncthreads();
     if (out_heads) {
@@ -329,20 +354,20 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
                         float *o = out_heads + (((size_t)gb * 2 + head) * 32 + 8 * q + 4 * h) * CELLS + cell;
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            o[i * CELLS] = fmaxf(__builtin_fmaf(h2[t][4 * q + i], HR_LO_INV, h1[t][4 * q + i]) + b[i], 0.0f);
+                            o[i * CELLS] = fmaxf(__builtin_fmaf(h1[t][4 * q + i] + h2[t][4 * q + i], head_scale, b[i]), 0.0f);
                     }
                 }
             }
         }
         return;
     }
-    for (int p = threadIdx.x; p < NCOL * 32; p += 256) {   // activations [column][128] f32 = hi + lo * 2^-11
+    for (int p = threadIdx.x; p < NCOL * 32; p += 256) {   // activations [column][128] f32 = (hi + lo) * 2^-ka
         const int col = p >> 5, ch4 = p & 31;
         if (g0 + col / CELLS < n_live) {
             const u32x2 ph = *(const u32x2 *)(lds + col * HR_ROW_BYTES + ch4 * 8);
             const u32x2 pl = *(const u32x2 *)(lds + GEO::PART_BYTES + col * HR_ROW_BYTES + ch4 * 8);
             const f32x2 v01 = join_pair(ph.x, pl.x), v23 = join_pair(ph.y, pl.y);
-            *(f32x4 *)(out + ((size_t)g0 * CELLS + col) * HR_CH + ch4 * 4) = (f32x4){v01.x, v01.y, v23.x, v23.y};
+            *(f32x4 *)(out + ((size_t)g0 * CELLS + col) * HR_CH + ch4 * 4) = (f32x4){v01.x, v01.y, v23.x, v23.y} * out_scale;
         }
     }
 }
@@ -351,9 +376,10 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
 template <int R_, int TB_, int D_, int NV_>
 static int launch_hr(const float *planes, const void *weights, const void *head_w, const float *bias, float *out, float *out_heads,
-                     const int *rows, const int *n_rows, int G, int n_layers, yy_stream_t s) {
+                     const int *rows, const int *n_rows, int G, int n_layers, const float (&sc)[4], yy_stream_t s) {
     thr::k_tower_h3r<R_, TB_, D_, NV_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
-        planes, (const unsigned char *)weights, (const unsigned char *)head_w, bias, out, out_heads, rows, n_rows, G, n_layers);
+        planes, (const unsigned char *)weights, (const unsigned char *)head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc[0],
+        sc[1], sc[2], sc[3]);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3_regs: launch failed");
     return YY_OK;
 }
@@ -362,15 +388,17 @@ static int launch_hr(const float *planes, const void *weights, const void *head_
 // NULL with out_heads NULL; bias f32 [n_layers (+1), 128]; planes f32 [G,5,R,R]; out f32 [G,R,R,128] or out_heads f32 [G,2,32,R*R].
 extern "C" int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, const void *head_w, const float *bias, float *out,
                                       float *out_heads, const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
-                                      int channels, int n_layers, yy_stream_t s) {
+                                      int channels, int n_layers, int weight_exp, int head_exp, int act_exp, yy_stream_t s) {
     if (G == 0) return YY_OK;
+    // {input scale 2^ka, accumulator scale 2^-kw, head accumulator scale 2^-(kh+ka), output scale 2^-ka}
+    const float sc[4] = {ldexpf(1.0f, act_exp), ldexpf(1.0f, -weight_exp), ldexpf(1.0f, -(head_exp + act_exp)), ldexpf(1.0f, -act_exp)};
     if (!planes || !weights || !bias || (!out && !out_heads) || (out_heads && !head_w) || G < 0 || (rows && !n_rows))
         return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_f16x3_regs: bad argument");
     if (R != C || (R != 6 && R != 8 && R != 12) || channels != HR_CH || n_layers < 1 ||
         n_layers + (out_heads ? 1 : 0) > HR_MAX_LAYERS || (n_layers & 1) == 0)
         return yy_tower_set_err(YY_E_UNSUPPORTED,
                                 "yy_nn_tower_f16x3_regs: needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks");
-    if (R == 8) return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-    if (R == 6) return launch_hr<6, 4, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, s);
-    return launch_hr<12, 1, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, s);
+    if (R == 8) return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
+    if (R == 6) return launch_hr<6, 4, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
+    return launch_hr<12, 1, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
 }

@@ -176,7 +176,7 @@ def tower_forward_x3(planes, weights, bias, n_layers):
     return out.permute(0, 3, 1, 2)
 
 
-def tower_forward_h3(planes, weights, bias, n_layers):
+def tower_forward_h3(planes, weights, bias, n_layers, exps):
     """Stem + residual tower at float32 accuracy on the f16 MFMA (split-f16, csrc/yy_tower_h3.hip / yy_tower_h3q.hip).
     planes f32 [G,5,R,R] (R = 6, 8, 12) -> f32 activations as a channels-last tensor [G,128,R,R]."""
     G, _, R, Cc = planes.shape
@@ -185,14 +185,16 @@ def tower_forward_h3(planes, weights, bias, n_layers):
     _need(bias, torch.float32, (n_layers, 128), "tower bias")
     out = torch.empty((G, R, Cc, 128), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_f16x3(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, _stream()))
+        check(lib().yy_nn_tower_f16x3(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, int(exps[0]), int(exps[2]),
+                                      _stream()))
     return out.permute(0, 3, 1, 2)
 
 
-def tower_heads_forward_h3(planes, weights, bias, n_layers, rows=None, n_rows=None, out=None):
+def tower_heads_forward_h3(planes, weights, bias, n_layers, exps, rows=None, n_rows=None, out=None):
     """Split-f16 tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] -> f32 [G,2,32*R*R] = (policy features, value
     features) in the reference's flatten order.  rows int32 [G] / n_rows int32 [1] (device): evaluate planes[rows[i]] for
-    i < n_rows into output row i (the other output rows are left untouched)."""
+    i < n_rows into output row i (the other output rows are left untouched).  exps = (kw, kh, ka): the power-of-two scales of
+    the packed weights / head weights / activations (network.pack_tower_h3)."""
     G, _, R, Cc = planes.shape
     _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     _need(weights, torch.int16, (9 + 36 * (n_layers - 1) + 2, 8192), "split-f16 tower+heads weights")
@@ -205,11 +207,11 @@ def tower_heads_forward_h3(planes, weights, bias, n_layers, rows=None, n_rows=No
     _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
     with torch.cuda.device(planes.device):
         check(lib().yy_nn_tower_heads_f16x3(_p(planes), _p(weights), _p(bias), _p(out), _p(rows), _p(n_rows), G, R, Cc, 128,
-                                            n_layers, _stream()))
+                                            n_layers, int(exps[0]), int(exps[1]), int(exps[2]), _stream()))
     return out
 
 
-def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, rows=None, n_rows=None, out=None):
+def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, exps, rows=None, n_rows=None, out=None):
     """tower_heads_forward_h3 with the weight stream in registers (csrc/yy_tower_h3r.hip; boards 6x6 / 8x8 / 12x12); weights in
     the wave-major order of network.pack_tower_h3r / pack_heads_h3r.  Same bits."""
     G, _, R, Cc = planes.shape
@@ -225,11 +227,11 @@ def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, rows=None, 
     _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
     with torch.cuda.device(planes.device):
         check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), _p(head_w), _p(bias), None, _p(out), _p(rows), _p(n_rows), G, R, Cc,
-                                           128, n_layers, _stream()))
+                                           128, n_layers, int(exps[0]), int(exps[1]), int(exps[2]), _stream()))
     return out
 
 
-def tower_forward_h3r(planes, weights, bias, n_layers):
+def tower_forward_h3r(planes, weights, bias, n_layers, exps):
     """Tower activations f32 [G,128,R,R] (channels-last memory) from the register-ring kernel (tests)."""
     G, _, R, Cc = planes.shape
     _need(planes, torch.float32, (G, 5, R, Cc), "planes")
@@ -238,7 +240,7 @@ def tower_forward_h3r(planes, weights, bias, n_layers):
     out = torch.empty((G, R, Cc, 128), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
         check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), None, _p(bias), _p(out), None, None, None, G, R, Cc, 128, n_layers,
-                                           _stream()))
+                                           int(exps[0]), 0, int(exps[2]), _stream()))
     return out.permute(0, 3, 1, 2)
 
 

@@ -206,35 +206,44 @@ def pack_tower_x3(net):
     return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
 
 
-LO_SCALE = 2048.0      # csrc/yy_tower_h3.hip: lo = f16((x - hi) * 2^11)
+ACT_EXP = 3          # split-f16 tower: activations (and the tower's bias rows) live times 2^ACT_EXP (csrc/yy_tower_h3.hip)
+
+
+def _pow2_exponent(t, target=14):
+    """k such that max|t| * 2^k lies in [2^(target-1), 2^target): an exact scaling that keeps the float16 lo parts normal."""
+    m = float(t.abs().max())
+    if not np.isfinite(m) or m <= 0.0:
+        return 0
+    return int(target - 1 - np.floor(np.log2(m)))
 
 
 def split_f16(t):
-    """x -> (hi, lo) float16 with x == hi + lo * 2^-11 to 22 significant bits (csrc/yy_tower_h3.hip)."""
+    """x -> (hi, lo) float16 with x == hi + lo to 22 significant bits (csrc/yy_tower_h3.hip): hi = f16(x), lo = f16(x - hi)."""
     t = t.float()
     hi = t.to(torch.float16)
     if not bool(torch.isfinite(hi).all()):
-        raise ValueError("split-f16 evaluator: a folded weight exceeds the float16 range (|w| > 65504)")
-    lo = ((t - hi.float()) * LO_SCALE).to(torch.float16)
+        raise ValueError("split-f16 evaluator: a scaled weight exceeds the float16 range")
+    lo = (t - hi.float()).to(torch.float16)
     return hi, lo
 
 
 def pack_tower_h3(net):
-    """Split-f16 packing for csrc/yy_tower_h3.hip (evaluator mode "f16x3"): every folded float32 weight w becomes
-    hi = f16(w), lo = f16((w - hi) * 2^11); chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] f16 with
+    """Split-f16 packing for csrc/yy_tower_h3q.hip (evaluator mode "f16x3"): every folded float32 weight w, times 2^kw, becomes
+    hi = f16(w'), lo = f16(w' - hi); chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] f16 with
     cout = nt*32 + c and cin = quarter*32 + ks*16 + h*8 + j (part 0 = hi, 1 = lo); the stem has one chunk per tap (5 planes
     padded to 16 channels, ks = 0 only), every other layer 36 (tap-major, then quarter).
-    Returns int16 [n_chunks, 8192] (f16 bits), float32 bias [n_layers, 128]."""
+    Returns (int16 [n_chunks, 8192] f16 bits, float32 bias [n_layers, 128] times 2^ACT_EXP, kw)."""
     convs = [(net.conv1, net.bn1)]
     for blk in net.res_blocks:
         convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    folded = [fold_batchnorm(conv, bn) for conv, bn in convs]
+    kw = _pow2_exponent(torch.cat([w.float().reshape(-1) for w, _ in folded]))
     chunks, biases = [], []
-    for li, (conv, bn) in enumerate(convs):
-        w, b = fold_batchnorm(conv, bn)
+    for li, (w, b) in enumerate(folded):
         w = w.float().cpu()
         wp = torch.zeros((128, 128, 3, 3))
         wp[:, :w.shape[1]] = w
-        hi, lo = split_f16(wp)
+        hi, lo = split_f16(torch.ldexp(wp, torch.tensor(kw)))
         for tap in range(9):
             parts = []
             for t in (hi, lo):
@@ -243,36 +252,38 @@ def pack_tower_h3(net):
             both = torch.stack(parts, dim=2).contiguous()                          # quarter, ks, part, nt, h, c, j
             for quarter in range(1 if li == 0 else 4):
                 chunks.append(both[quarter].reshape(-1))
-        biases.append(b.float().cpu())
-    return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
+        biases.append(torch.ldexp(b.float().cpu(), torch.tensor(ACT_EXP)))
+    return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous(), kw
 
 
 def pack_heads_h3(net):
-    """The two 1x1 head convolutions for csrc/yy_tower_h3.hip / yy_tower_h3q.hip: two chunks [ks 4][part 2][nt 2][h 2][c 32][j 8]
-    f16 (nt 0 = policy channels, nt 1 = value channels, cin = chunk*64 + ks*16 + h*8 + j) and one bias row
-    [policy 32 | value 32 | zeros]."""
+    """The two 1x1 head convolutions for the split-f16 kernels: two chunks [ks 4][part 2][nt 2][h 2][c 32][j 8] f16 of the
+    weights times 2^kh (nt 0 = policy channels, nt 1 = value channels, cin = chunk*64 + ks*16 + h*8 + j) and one UNSCALED bias
+    row [policy 32 | value 32 | zeros].  Returns (int16 [2, 8192], float32 [1, 128], kh)."""
     wp, bp = fold_batchnorm(net.policy_conv, net.policy_bn)      # [32,128,1,1]
     wv, bv = fold_batchnorm(net.value_conv, net.value_bn)
-    w = torch.cat([wp, wv]).float().cpu().reshape(2, 32, 2, 4, 2, 8)            # nt, c, chunk, ks, h, j
+    w = torch.cat([wp, wv]).float().cpu()
+    kh = _pow2_exponent(w)
+    w = torch.ldexp(w, torch.tensor(kh)).reshape(2, 32, 2, 4, 2, 8)              # nt, c, chunk, ks, h, j
     parts = [t.permute(2, 3, 0, 4, 1, 5) for t in split_f16(w)]                  # chunk, ks, nt, h, c, j
     both = torch.stack(parts, dim=2).contiguous()                                # chunk, ks, part, nt, h, c, j
     bias = torch.zeros(1, 128)
     bias[0, :32], bias[0, 32:64] = bp.float().cpu(), bv.float().cpu()
-    return both.reshape(2, -1).view(torch.int16).contiguous(), bias
+    return both.reshape(2, -1).view(torch.int16).contiguous(), bias, kh
 
 
 def pack_tower_h3r(net):
     """pack_tower_h3 re-ordered "wave-major" for csrc/yy_tower_h3r.hip (weights loaded global -> VGPR by the wave that uses
     them): chunk = [nt 4][ks 2][part 2][h 2][c 32][j 8] f16, so that the 4 KB of output-channel quarter nt are contiguous."""
-    wq, bq = pack_tower_h3(net)
+    wq, bq, kw = pack_tower_h3(net)
     n = wq.shape[0]
-    return wq.view(n, 2, 2, 4, 512).permute(0, 3, 1, 2, 4).contiguous().view(n, 8192), bq
+    return wq.view(n, 2, 2, 4, 512).permute(0, 3, 1, 2, 4).contiguous().view(n, 8192), bq, kw
 
 
 def pack_heads_h3r(net):
     """pack_heads_h3 re-ordered for csrc/yy_tower_h3r.hip: [head 2][ks 8][part 2][h 2][c 32][j 8] f16 (cin = ks*16 + h*8 + j)."""
-    hw, hb = pack_heads_h3(net)                                      # [chunk 2][ks 4][part 2][nt 2][512]
-    return hw.view(2, 4, 2, 2, 512).permute(3, 0, 1, 2, 4).contiguous().view(2, 8192), hb
+    hw, hb, kh = pack_heads_h3(net)                                  # [chunk 2][ks 4][part 2][nt 2][512]
+    return hw.view(2, 4, 2, 2, 512).permute(3, 0, 1, 2, 4).contiguous().view(2, 8192), hb, kh
 
 
 def pack_heads(net):
@@ -300,8 +311,8 @@ class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
     mode "auto" (default): `reference_precision_mode(net)` -- "f16x3" where the kernels cover the shape, else "fp32".
-    mode "f16x3": float32 ACCURACY on the f16 matrix cores (csrc/yy_tower_h3.hip / yy_tower_h3q.hip): activations and weights
-    as hi + lo*2^-11 float16 pairs (22 significant bits), three MFMAs per product term, f32 accumulation / bias / residual,
+    mode "f16x3": float32 ACCURACY on the f16 matrix cores (csrc/yy_tower_h3.hip, yy_tower_h3r.hip, yy_tower_h3q.hip): activations
+    and weights as hi + lo float16 pairs (22 significant bits), three MFMAs per product term, f32 accumulation / bias / residual,
     1x1 head convs fused, FC heads as float32 GEMMs + one finish kernel.  Searches driven by it return the reference's visit
     counts (tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi); supports row compaction.
     mode "fp32": the module as is (same arithmetic as predict()).
@@ -332,7 +343,8 @@ class BatchedEvaluator:
             if tuple(net.board_size) not in H3_BOARDS or net.conv1.out_channels != 128 or len(net.res_blocks) > 10 \
                     or net.policy_conv.out_channels != 32:
                 raise ValueError("f16x3 needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks")
-            (wq, bq), (hw, hb) = pack_tower_h3(net), pack_heads_h3(net)
+            (wq, bq, kw), (hw, hb, kh) = pack_tower_h3(net), pack_heads_h3(net)
+            self.h3_exps = (kw, kh, ACT_EXP)     # weights x 2^kw, head weights x 2^kh, activations x 2^ACT_EXP
             self.h3_w = torch.cat([wq, hw]).contiguous().to(self.device)
             self.h3_b = torch.cat([bq, hb]).contiguous().to(self.device)
             self.h3_layers = 1 + 2 * len(net.res_blocks)
@@ -431,9 +443,9 @@ class BatchedEvaluator:
             if needs_eval is not None:
                 rows, n = engine.compact_rows(needs_eval)
             if planes.shape[0] > self.h3r_min_rows and self.use_h3r:
-                feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, rows, n)
+                feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, self.h3_exps, rows, n)
             else:
-                feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, rows, n)   # [G, 2, 32*cells] f32
+                feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, self.h3_exps, rows, n)   # [G, 2, 32*cells] f32
             logits = torch.addmm(self.pfc_b, feats[:, 0], self.pfc_wt)                                    # [G, A]
             hidden = torch.addmm(self.vfc1_b, feats[:, 1], self.vfc1_wt)                                  # [G, 256]
             return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n)
