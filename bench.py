@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 / f16 MFMA ~2.5 PFLOP/s dense
 MFMA_F32_PEAK_TFLOPS = 157.3    # same guide: f32-input MFMA = the f32 vector rate
 NN_MODES = ["f16x3", "bf16", "fp16", "fp32", "fp32t", "bf16x3"]
-FP32_GRADE = {"f16x3": "float32-accurate split-f16 MFMA (hi + lo*2^-11 float16 pairs, f32 accumulate)",
+FP32_GRADE = {"f16x3": "float32-accurate split-f16 MFMA (hi + lo float16 pairs = 22 significant bits, f32 accumulate)",
               "fp32t": "exact float32 MFMA", "fp32": "float32 (PyTorch/MIOpen)"}
 
 

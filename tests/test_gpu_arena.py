@@ -148,6 +148,7 @@ def test_cli_self_play_config1(tmp_path):
         z = np.load(info["data_file"])
         n = z["boards"].shape[0]
         assert z["boards"].shape == (n, 6, 6) and z["policies"].shape == (n, 36) and z["values"].shape == (n,)
+        print("config 1 CLI,", extra or "default engine semantics", "->", n, "examples")
         assert lo <= n <= hi and len(np.unique(z["game_id"])) == 4
         assert np.allclose(z["policies"].sum(1), 1.0, atol=1e-6)
         os.remove(info["data_file"])

@@ -322,7 +322,7 @@ def _module_f64(net, planes):
 
 @pytest.mark.parametrize("R", [8, 6, 12])
 def test_split_f16_tower_kernel_is_float32_grade(R):
-    """csrc/yy_tower_h3.hip (activations and weights as hi + lo*2^-11 float16 pairs, three f16 MFMAs per product term, two
+    """csrc/yy_tower_h3*.hip (activations and weights as hi + lo float16 pairs, three f16 MFMAs per product term, two
     f32 accumulators) against the module evaluated in FLOAT64: 22 significant bits per operand, so the error must be that
     of float32 arithmetic itself.  Bounds: tower activations within 2e-6 of the layer scale (measured ~4e-7; the float32
     module measures ~3e-7 on the same inputs), policy and value within 2e-6 abs (north-star: 1e-5)."""

@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--slots", type=int, default=4096)
 ap.add_argument("--sims", type=int, default=800)
-ap.add_argument("--nn", default="bf16")
+ap.add_argument("--nn", default="auto", help="auto = float32-accurate (f16x3); bf16 = reduced precision")
 ap.add_argument("--rows", type=int, default=8)
 ap.add_argument("--single", action="store_true", help="only the plain run (no 2x refilled run)")
 ap.add_argument("--out", default="gpurun_out/config2_full.json")

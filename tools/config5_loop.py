@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--arena-games", type=int, default=40)
-    ap.add_argument("--nn", default="bf16")
+    ap.add_argument("--nn", default="auto", help="auto = float32-accurate (f16x3); bf16 = reduced precision")
     ap.add_argument("--out", default="gpurun_out/config5.json")
     a = ap.parse_args()
     import torch
