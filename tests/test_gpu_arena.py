@@ -135,23 +135,33 @@ def test_cli_self_play_config1(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     mdir, ddir = tmp_path / "models", tmp_path / "data"
     cmd = [sys.executable, os.path.join(root, "train_alphazero.py"), "--mode", "self-play", "--rows", "6", "--cols", "6",
-           "--simulations", "25", "--episodes", "4", "--workers", "1", "--model-dir", str(mdir), "--data-dir", str(ddir),
-           "--nn", "fp32"]
+           "--simulations", "25", "--episodes", "4", "--workers", "1", "--model-dir", str(mdir), "--data-dir", str(ddir)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "Model file not found" in (r.stderr + r.stdout)
     torch.manual_seed(0)
     pkg.YinYangNeuralNetwork(pkg.YinYangGame(6, 6)).save_model(str(mdir / "best_model.pth.tar"))
+    # The batched engine draws noise and moves from per-game counter streams (csrc/yy_selfplay.hip), not from numpy's global
+    # stream, so the number of examples differs from one run of the reference (BASELINE.md measured 4 = one example per game
+    # for ITS stream in literal mode; the reference-API SelfPlayWorker, which does use numpy's stream, is pinned move by move
+    # by the G4 transcripts).  What the file-level test can hold exactly: the run is a pure function of (seed, model) -- two
+    # invocations write identical arrays -- and every game contributes between 1 and 36 (+ passes) examples.
     for extra, lo, hi in (([], 40, 37 * 4), (["--board-semantics", "aliased", "--reference-quirks"], 4, 60)):
-        r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        info = json.loads(r.stdout.strip().splitlines()[-1])
-        z = np.load(info["data_file"])
-        n = z["boards"].shape[0]
-        assert z["boards"].shape == (n, 6, 6) and z["policies"].shape == (n, 36) and z["values"].shape == (n,)
+        files = []
+        for rep in range(2):
+            r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            info = json.loads(r.stdout.strip().splitlines()[-1])
+            z = np.load(info["data_file"])
+            files.append({k: z[k] for k in z.files})
+            os.remove(info["data_file"])
+        a, b = files
+        n = a["boards"].shape[0]
         print("config 1 CLI,", extra or "default engine semantics", "->", n, "examples")
-        assert lo <= n <= hi and len(np.unique(z["game_id"])) == 4
-        assert np.allclose(z["policies"].sum(1), 1.0, atol=1e-6)
-        os.remove(info["data_file"])
+        assert a["boards"].shape == (n, 6, 6) and a["policies"].shape == (n, 36) and a["values"].shape == (n,)
+        assert lo <= n <= hi and len(np.unique(a["game_id"])) == 4
+        assert np.allclose(a["policies"].sum(1), 1.0, atol=1e-6)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k          # same seed, same model -> the same file, bit for bit
 
 
 def test_bench_json_contract(tmp_path):

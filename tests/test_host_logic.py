@@ -152,6 +152,14 @@ q = TrainingDataQueue()
 q.push_file(path)
 assert len(q) == 10
 assert not [f for f in os.listdir(sys.argv[2]) if ".tmp" in f]
+# ... and the training sample drawn from it is the SAME on every rank (rank 0's indices are broadcast): equal queue lengths,
+# equal sample sizes, equal contents -- what DDP's collectives need
+import random
+random.seed(100 + r)                      # different host RNG states on purpose
+smp = q.sample(6)
+both = [None, None]
+dist.all_gather_object(both, (len(q), smp["states"].tolist(), smp["values"].tolist()))
+assert both[0] == both[1], "ranks drew different training samples"
 dist.destroy_process_group()
 print("rank", r, "ok")
 '''
