@@ -42,6 +42,15 @@ extern "C" {
                               it, exactly like the reference (yin_yang_game.py:52-58 +
                               ai/mcts.py:385-397).  Default (flag clear) = "copied": every
                               expanded node owns its board. */
+#define YY_FLAG_REUSE_PASS_VALUE 4u /* copied boards only (yy_mcts_create refuses it with YY_FLAG_ALIASED).  The
+                              reference evaluates a non-terminal node without legal moves again on EVERY visit
+                              (ai/mcts.py:93-95 is_expanded() is False without children, :371-397 evaluate + expand).
+                              With copied boards the node's position never changes, so the evaluator returns the
+                              same value each time; with this flag the value of the first evaluation is kept in the
+                              node record and a revisit takes it from there: no planes written, needs_eval = 0,
+                              counters[6] += 1.  Visit counts, value sums and pi are unchanged (tests/test_gpu_mcts.py
+                              ::test_pass_value_reuse_*); counters[0] (evaluator rows) gets smaller.  Default off:
+                              the evaluator call sequence is then the reference's, row for row. */
 
 typedef void *yy_stream_t;
 
@@ -160,7 +169,7 @@ int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
  * NaN priors or a NaN value from the evaluator; such a game stops searching, and the flag is sticky: yy_mcts_begin
  * does not clear it, only this call does -- and
  * counters[8] = {evaluator rows requested, selection levels walked, children scanned during
- * selection, children created, terminal revisits, nodes created, 0, 0} accumulated since create
+ * selection, children created, terminal revisits, nodes created, pass values reused, 0} accumulated since create
  * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
 int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
 int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);

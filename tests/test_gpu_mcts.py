@@ -207,15 +207,16 @@ def test_arena_overflow_is_a_status(pkg):
     m.close()
 
 
+@pytest.mark.parametrize("sims", [96, 800])
 @pytest.mark.parametrize("copied", [1, 0], ids=["copied", "aliased"])
-def test_full_size_batch_4096_games(pkg, copied):
-    """BASELINE config[1] batch size: G = 4096 concurrent 8x8 games searched together (device-side hash
+def test_full_size_batch_4096_games(pkg, copied, sims):
+    """BASELINE config[1] at its full size -- G = 4096 concurrent 8x8 games, 800 simulations (and a 96-simulation case) -- searched together (device-side hash
     evaluator, fused step kernel), a random subset checked bit-for-bit against the CPU oracle, plus
     size-independent invariants on all games: root.visits == sims, sum(counts) == sims for non-terminal
     roots, pi sums to 1, counts only on legal moves, boards unchanged in copied mode."""
     import torch
     from hash_eval import hash_eval_torch
-    G, R, C, sims = 4096, 8, 8, 96
+    G, R, C = 4096, 8, 8
     rng = np.random.default_rng(77 + copied)
     # staggered positions: random legal play for (g mod 40) plies, generated with the HIP rules kernels
     E = pkg.engine
@@ -255,6 +256,75 @@ def test_full_size_batch_4096_games(pkg, copied):
         assert np.array_equal(c[g], r.counts), g
         assert np.array_equal(fb[g].cpu().numpy(), r.final_board), g
     m.close()
+
+
+def _late_positions(E, G, R, C, max_ply, seed):
+    """random legal play for (g mod max_ply) plies with the HIP rules kernels; a side without a move passes"""
+    import torch
+    boards = torch.zeros((G, R, C), dtype=torch.int8, device="cuda")
+    players = torch.ones(G, dtype=torch.int8, device="cuda")
+    target = torch.arange(G, device="cuda") % max_ply
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    for ply in range(max_ply):
+        mask = E.valid_mask(boards, players).float()
+        has = mask.sum(1) > 0
+        act = torch.multinomial(torch.where(has[:, None], mask, torch.ones_like(mask)), 1, generator=gen).reshape(-1).to(torch.int32)
+        act = torch.where(has, act, torch.full_like(act, -1)).contiguous()
+        old_b, old_p = boards.clone(), players.clone()
+        E.step_(boards, players, act)                      # an action of -1 places nothing and flips the side: a pass
+        adv = ply < target
+        boards = torch.where(adv[:, None, None], boards, old_b).contiguous()
+        players = torch.where(adv, players, old_p).contiguous()
+    return boards, players
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
+def test_pass_value_reuse_returns_the_same_search(pkg, fused):
+    """YY_FLAG_REUSE_PASS_VALUE (include/yy_engine.h): a childless non-terminal node -- the reference evaluates it again on
+    every visit, ai/mcts.py:93-95, 371-397 -- keeps the value of its first evaluation.  Late-game 8x8 positions (where such
+    nodes are common, pass ROOTS included): visit counts, root statistics and pi are identical to the plain search and to the
+    oracle (= the reference's evaluation sequence), the evaluator is asked for `reused_values` fewer rows, and those rows are
+    not flagged in needs_eval."""
+    import torch
+    from hash_eval import hash_eval_torch
+    E = pkg.engine
+    G, R, C, sims = 768, 8, 8, 200
+    boards, players = _late_positions(E, G, R, C, 60, 9)
+    legal = E.valid_mask(boards, players).cpu().numpy()
+    ended = E.game_ended(boards, players).cpu().numpy()
+    pass_roots = (legal.sum(1) == 0) & (ended == 0)
+    assert pass_roots.sum() >= 3 and (ended != 0).sum() >= 3          # the batch holds pass roots and finished games too
+    res = {}
+    for reuse in (False, True):
+        m = E.BatchedMCTS(G, R, C, sims, reuse_pass_value=reuse)
+        rows = []
+
+        def ev(planes, m=m, rows=rows):
+            rows.append(int(m.needs_eval.sum()))
+            return hash_eval_torch(planes, 6, 4)
+
+        counts = m.search(boards, players, ev, sims, fused=fused)
+        visits, wsum = m.root_stats()
+        res[reuse] = (counts.cpu().numpy(), visits.cpu().numpy(), wsum.cpu().numpy(), m.root_policy().cpu().numpy(), m.status(), rows)
+        m.close()
+    (c0, n0, w0, p0, k0, r0), (c1, n1, w1, p1, k1, r1) = res[False], res[True]
+    assert np.array_equal(c0, c1) and np.array_equal(n0, n1) and np.array_equal(w0, w1) and np.array_equal(p0, p1)
+    assert k0["reused_values"] == 0 and k1["reused_values"] > 0.05 * k0["evals"]
+    assert k1["evals"] + k1["reused_values"] == k0["evals"]
+    assert k1["nodes"] == k0["nodes"] and k1["terminal_revisits"] == k0["terminal_revisits"]
+    assert sum(r1[1:]) == k1["evals"] and sum(r0[1:]) == k0["evals"]      # needs_eval flags exactly the rows that are evaluated (call 0 = the root call)
+    # (a pass root is evaluated by the root call of mcts.py:288 and by its first simulation, then never again)
+    bh, ph = boards.cpu().numpy(), players.cpu().numpy()
+    for g in list(np.flatnonzero(pass_roots)[:3]) + list(np.random.default_rng(3).choice(G, 24, replace=False)):
+        r = O.search_hash(bh[g], int(ph[g]), sims, 1, 6, 4)
+        assert np.array_equal(c1[g], r.counts), g
+
+
+def test_pass_value_reuse_needs_copied_boards(pkg):
+    with pytest.raises(pkg._lib.YYError) as ei:
+        pkg.engine.BatchedMCTS(4, 6, 6, 10, aliased=True, reuse_pass_value=True)
+    assert ei.value.code == -1
 
 
 def test_search_with_rowcol_rule_vs_oracle(pkg):

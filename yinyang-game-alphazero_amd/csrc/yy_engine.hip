@@ -441,9 +441,10 @@ extern "C" int yy_rules_mask_terminal_bb(const uint64_t *black, const uint64_t *
 }
 
 // =============================================================================== MCTS context
-enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5 };
+enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5, K_REUSE = 6 };
 #define CHILD_NONE 0x00FFFFFFu
 #define NF_TERMINAL 1u
+#define NF_HASVALUE 2u   // pass node whose evaluator value is kept in the record's .z (YY_FLAG_REUSE_PASS_VALUE)
 
 struct GameState {
     int32_t n_nodes, n_edges;
@@ -461,7 +462,7 @@ struct GameState {
     uint8_t err_ever;       // sticky: set with err, survives yy_mcts_begin, cleared only by yy_mcts_status
     uint64_t leaf_board[2 * YY_MAX_NW];
     uint64_t leaf_mask[YY_MAX_NW];
-    uint64_t ctr[6];        // evals, levels, children scanned, children created, terminal revisits, nodes
+    uint64_t ctr[7];        // evals, levels, children scanned, children created, terminal revisits, nodes, reused pass values
 };
 
 struct yy_mcts {
@@ -481,7 +482,7 @@ struct yy_mcts {
 struct MctsDev {  // by-value kernel argument
     YYGeo geo;
     int32_t G;
-    uint32_t aliased;
+    uint32_t aliased, reuse;
     float cpuct;
     double eps;
     int64_t node_cap, edge_cap, path_cap;
@@ -498,6 +499,7 @@ static MctsDev make_dev(const yy_mcts *c) {
     d.geo = c->geo;
     d.G = c->cfg.G;
     d.aliased = (c->cfg.flags & YY_FLAG_ALIASED) ? 1u : 0u;
+    d.reuse = (c->cfg.flags & YY_FLAG_REUSE_PASS_VALUE) ? 1u : 0u;
     d.cpuct = c->cfg.cpuct;
     d.eps = 0.0;
     d.node_cap = c->node_cap;
@@ -613,7 +615,13 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         const uint32_t hy = rfl(hdr.y);
         const int k = node_k(hy), first = rfl((int)hdr.x);
         if (node_flags(hy) & NF_TERMINAL) { kind = K_TERMINAL; break; }            // mcts.py:360, 365
-        if (k == 0) { kind = (node == 0) ? K_ROOTPASS : K_REEXPAND; break; }      // mcts.py:93-95
+        if (k == 0) {                                                              // mcts.py:93-95
+            // A node without children is evaluated again on every visit.  With copied boards its board never changes,
+            // so that evaluation returns the value it returned the first time: YY_FLAG_REUSE_PASS_VALUE takes it from
+            // the node record instead of spending an evaluator row on it (same statistics, fewer rows).
+            kind = (d.reuse && (node_flags(hy) & NF_HASVALUE)) ? K_REUSE : (node == 0) ? K_ROOTPASS : K_REEXPAND;
+            break;
+        }
         if (depth >= (int)d.path_cap) { kind = K_NONE; if (lane == 0) st->err = st->err_ever = 1; break; }
         // ---- Node.select_child (mcts.py:97-145), float32 order of SURVEY 8a/a12
         // sum of child visits (mcts.py:112).  Copied boards: every visit of an expanded node after its
@@ -728,6 +736,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         st->ctr[2] += c_scan;
         if (need) st->ctr[0] += 1;
         if (kind == K_TERMINAL) st->ctr[4] += 1;
+        if (kind == K_REUSE) st->ctr[6] += 1;
         if (needs_eval) needs_eval[g] = need;
     }
 }
@@ -750,6 +759,8 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
     if (kind == K_TERMINAL) {
         v = rflf(__uint_as_float(nodes[node].z));                                   // mcts.py:366
         v_is_py = true;
+    } else if (kind == K_REUSE) {
+        v = rflf(__uint_as_float(nodes[node].z));                                   // the np.float32 the evaluator returned for this node
     } else {
         v = (kind == K_ROOTINIT) ? 0.0f : rflf(value[g]);
         if (v != v) {   // a NaN from the evaluator must not enter the statistics: the game stops searching, the error is sticky
@@ -821,7 +832,12 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                 return;
             }
             if (lane == 0) {
-                nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, 0, lplayer), 0u, 0u);
+                // a pass node keeps its value (not from the root call of mcts.py:288: that value is discarded and
+                // yy_mcts_expand_root is not given it -- a pass root keeps the value of its first simulation)
+                const bool hold = d.reuse && k == 0 && kind != K_ROOTINIT;
+                const float keepv = hold ? v : 0.0f;
+                nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, hold ? NF_HASVALUE : 0u, lplayer),
+                                         hold ? __float_as_uint(keepv) : 0u, 0u);
                 st->ctr[3] += (uint64_t)k;
             }
             n_edges += k;
@@ -946,22 +962,22 @@ template <int NW> __global__ void __launch_bounds__(64) k_get_boards(MctsDev d, 
     bb_to_board<NW>(boards + (size_t)g * d.geo.A, d.geo.A, b, w);
 }
 
-__global__ void k_status(MctsDev d, uint64_t *out /*[8]: 6 counters, overflow games, 0*/) {
-    uint64_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
+__global__ void k_status(MctsDev d, uint64_t *out /*[8]: 7 counters, overflow games*/) {
+    uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < d.G; g += gridDim.x * blockDim.x) {
         GameState *st = d.state + g;
-        for (int i = 0; i < 6; i++) acc[i] += st->ctr[i];
-        acc[6] += (st->err || st->err_ever) ? 1 : 0;   // a failure in ANY search since the last status call
+        for (int i = 0; i < 7; i++) acc[i] += st->ctr[i];
+        acc[7] += (st->err || st->err_ever) ? 1 : 0;   // a failure in ANY search since the last status call
         st->err_ever = 0;
     }
-    for (int i = 0; i < 7; i++)
+    for (int i = 0; i < 8; i++)
         if (acc[i]) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
 }
 
 __global__ void k_reset_counters(MctsDev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
-    for (int i = 0; i < 6; i++) d.state[g].ctr[i] = 0;
+    for (int i = 0; i < 7; i++) d.state[g].ctr[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------- host API
@@ -969,6 +985,8 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     if (!cfg || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
     if (int e = check_geo(cfg->G, cfg->R, cfg->C)) return e;
     if (cfg->max_sims < 1) return set_err(YY_E_INVALID, "max_sims < 1%s%s");
+    if ((cfg->flags & YY_FLAG_REUSE_PASS_VALUE) && (cfg->flags & YY_FLAG_ALIASED))
+        return set_err(YY_E_INVALID, "YY_FLAG_REUSE_PASS_VALUE needs copied boards: with the aliased board a node's position changes between visits%s%s");
     yy_mcts *c = new yy_mcts();
     memset(c, 0, sizeof *c);
     c->cfg = *cfg;
@@ -1124,11 +1142,11 @@ extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counter
     uint64_t h[8];
     HIP_TRY(hipMemcpy(h, c->scratch, sizeof h, hipMemcpyDeviceToHost));
     if (counters) {
-        for (int i = 0; i < 6; i++) counters[i] = h[i];
-        counters[6] = counters[7] = 0;
+        for (int i = 0; i < 7; i++) counters[i] = h[i];
+        counters[7] = 0;
     }
-    if (n_overflow) *n_overflow = (int32_t)h[6];
-    if (h[6]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
+    if (n_overflow) *n_overflow = (int32_t)h[7];
+    if (h[7]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
     return YY_OK;
 }
 

@@ -360,6 +360,10 @@ class BatchedEvaluator:
             self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
             self.use_h3r = True
             self.tower = False
+            # a row's (policy, value) is a function of that row's planes alone, bit for bit: the tower computes each board in a
+            # fixed order whatever its position in the batch (tests/test_gpu_network.py::test_split_f16_compaction_is_exact),
+            # so the search may reuse the value of a childless node instead of evaluating it again (YY_FLAG_REUSE_PASS_VALUE)
+            self.row_independent = True
             return
         if mode in ("fp32t", "bf16x3"):
             if tuple(net.board_size) != (8, 8) or net.conv1.out_channels != 128 or len(net.res_blocks) > 11:

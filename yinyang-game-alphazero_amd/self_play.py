@@ -118,7 +118,12 @@ class SelfPlayEngine:
     def __init__(self, game, evaluator, num_simulations=800, concurrent_games=4096, cpuct=1.0,
                  dirichlet_alpha=0.3, dirichlet_epsilon=0.25, temperature_threshold=10,
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
-                 device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None):
+                 device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None,
+                 reuse_pass_value=None):
+        """reuse_pass_value: None = on when the boards are copied and the evaluator declares `row_independent` (the split-f16
+        evaluator does): a node without legal moves is evaluated once and later visits take its stored value, where the
+        reference evaluates it again on every visit (ai/mcts.py:93-95, 371-397) and gets the same number.  The games played
+        are the same, move for move; the evaluator sees fewer rows."""
         assert board_semantics in ("aliased", "copied")
         self.game = game
         self.R, self.C = game.getBoardSize()
@@ -132,8 +137,11 @@ class SelfPlayEngine:
         self.rowcol = bool(getattr(game, "rowcol_rule", False))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.evaluator = evaluator
+        if reuse_pass_value is None:
+            reuse_pass_value = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
+        self.reuse_pass_value = bool(reuse_pass_value)
         self.ctx = engine.BatchedMCTS(self.G, self.R, self.C, self.sims, cpuct=cpuct, aliased=self.aliased,
-                                      rowcol=self.rowcol, device=self.device)
+                                      rowcol=self.rowcol, device=self.device, reuse_pass_value=self.reuse_pass_value)
         self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
         self.seed = int(seed)                      # key of the per-game counter streams (csrc/yy_selfplay.hip)
         self.n_alive = 0                           # live games, tracked on the host (no device read needed)
