@@ -165,11 +165,15 @@ def tower_launcher(eng):
         form = {8: "k_tower_h3r<8,2,9> (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
                 6: "k_tower_h3r<6,4,3>", 12: "k_tower_h3r<12,1,3>"}[eng.R]
         regs = G > ev.h3r_min_rows
-        return ((lambda: E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps)) if regs else
-                (lambda: E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)),
+
+        def launch(rows=None, n_rows=None):
+            if regs:
+                return E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n_rows)
+            return E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n_rows)
+        return (launch,
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
                        "peak = f16 MFMA dense peak / 3",
-                (2 * 9 * 16 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
+                (2 * 9 * 5 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
     if mode == "bf16x3":
         return (lambda: E.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers),
                 "k_tower_x3: stem + residual tower, split-bf16 (3 bf16 MFMAs per product term); peak = bf16 MFMA peak / 3",
@@ -216,7 +220,7 @@ def roofline_pass(eng):
         eng.evaluator(eng.ctx.planes)
     e1.record()
     torch.cuda.synchronize()
-    tower_ms = None
+    tower_ms, live = None, None
     tl = tower_launcher(eng)
     if tl is not None:      # the dominant kernel alone: HIP events on its launch stream
         tt = HipEventTimer(reps)
@@ -225,7 +229,17 @@ def roofline_pass(eng):
             tl[0]()
             tt.stop()
         tower_ms, _ = tt.mean_ms()
-    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms
+        if getattr(eng.evaluator, "supports_compaction", False):
+            # the launch as the lockstep step issues it: only the rows of the pending leaf batch that need an evaluation
+            from yinyang_game_alphazero_amd import engine as E
+            rows, n_rows = E.compact_rows(eng.ctx.needs_eval)
+            tt = HipEventTimer(reps)
+            for _ in range(reps):
+                tt.start()
+                tl[0](rows, n_rows)
+                tt.stop()
+            live = (tt.mean_ms()[0], int(n_rows.item()))
+    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms, live
 
 
 def algorithmic_bytes(counters, G, A, n_steps, nw):
@@ -391,7 +405,7 @@ def pmc_traffic(name, key):
 
 
 def make_roofline(args, eng, games):
-    k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms = roofline_pass(eng)
+    k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms, live = roofline_pass(eng)
     A = args.rows * args.cols
     nw = (A + 63) // 64
     # the counters cover the whole move = n_launch + 1 selections (the first one runs before the timed fused steps)
@@ -416,6 +430,12 @@ def make_roofline(args, eng, games):
                             "algorithmic_flops_per_launch": flops,
                             "timed": "20 launches on every row of the live leaf batch, hipEventRecord on the launch stream"},
                "roofline_tree_kernel": roof_tree}
+        if live is not None:      # what the lockstep step launches (and what a rocprofv3 summary of this command averages over)
+            lms, lrows = live
+            lach = flops / games * lrows / (lms * 1e-3) / 1e12
+            out["roofline"].update(live_rows=lrows, live_launch_ms=lms, live_achieved=lach, live_frac=lach / peak,
+                                   live_note="the same kernel on the compacted rows of one pending leaf batch (rows that need an "
+                                             "evaluation): the launch of the timed steps; fewer whole rounds of workgroups than the dense launch")
     Cc = args.channels
     flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
                   + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)

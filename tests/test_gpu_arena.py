@@ -195,6 +195,12 @@ def test_bench_json_contract(tmp_path):
     assert sec["nn"] == "bf16" and sec["value"] > 0 and "REDUCED" in sec["note"]
     tree = d["roofline_tree_kernel"]
     assert tree["bound"] == "hbm" and "traffic_source" in tree and 0 < tree["eval_fraction"] <= 1
+    # the launch as the timed steps issue it (compacted live rows), beside the dense one
+    assert 0 < rf["live_rows"] <= 256 and rf["live_launch_ms"] > 0 and abs(rf["live_frac"] - rf["live_achieved"] / rf["peak"]) < 1e-9
+    # the headline leg gives the evaluator every row the reference evaluates; the engine's pass-value reuse is a labelled extra leg
+    assert d["config"]["pass_value_reuse"] is False
+    ru = d["with_pass_value_reuse"]
+    assert ru["nn"] == "f16x3" and ru["value"] > 0 and ru["evaluator_rows_per_s"] > 0 and ru["eval_fraction"] <= tree["eval_fraction"] + 0.02
 
 
 # ---- arena against the reference's own AlphaZero.evaluate (alphazero.py:136-226), run unmodified with two hash evaluators
