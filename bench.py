@@ -172,7 +172,8 @@ def tower_launcher(eng):
             return E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n_rows)
         return (launch,
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
-                       "peak = f16 MFMA dense peak / 3",
+                       "peak = f16 MFMA dense peak / 3 (nominal, 2.4 GHz; hipBLASLt's dense f16 GEMM sustains 0.53 of nominal on "
+                       "this board under its power management: profiles/r02_power_probe.json)",
                 (2 * 9 * 5 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
     if mode == "bf16x3":
         return (lambda: E.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers),

@@ -98,6 +98,38 @@ def main():
                                  "mean_sclk_mhz": sum(fq) / len(fq) / 1e6 if fq else None, "samples": len(pw)}
         out[tag] = rec
         print(tag, json.dumps(rec))
+    # calibration: the vendor's dense f16 GEMM (hipBLASLt through torch.matmul) on the same box under the same cap
+    for n in (8192, 4096):
+        a = torch.randn(n, n, device="cuda", dtype=torch.float16)
+        b = torch.randn(n, n, device="cuda", dtype=torch.float16)
+        for _ in range(3):
+            a @ b
+        torch.cuda.synchronize()
+        s = Sampler(dirs)
+        s.start()
+        t_end = time.perf_counter() + SECONDS
+        n_mm, busy = 0, 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        while time.perf_counter() < t_end:
+            e0.record()
+            for _ in range(20):
+                a @ b
+            e1.record()
+            torch.cuda.synchronize()
+            busy += e0.elapsed_time(e1)
+            n_mm += 20
+        s.stop = True
+        s.join()
+        rows = s.rows[len(s.rows) // 4:]
+        rec = {"ms": busy / n_mm, "tflops": 2 * n ** 3 / (busy / n_mm * 1e-3) / 1e12}
+        for i, d in enumerate(dirs):
+            pw = [r[i][0] for r in rows if r[i][0] is not None]
+            fq = [r[i][1] for r in rows if r[i][1] is not None]
+            rec["card%d" % i] = {"mean_power_w": sum(pw) / len(pw) / 1e6 if pw else None,
+                                 "mean_sclk_mhz": sum(fq) / len(fq) / 1e6 if fq else None}
+        out["hipblaslt_f16_gemm_%d" % n] = rec
+        print("hipblaslt f16 gemm", n, json.dumps(rec))
+        del a, b
     print(smi(["--showpower", "--showclocks", "--showmaxpower"]))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/power_probe.json", "w"), indent=1)
