@@ -16,7 +16,7 @@ The headline leg runs the evaluator at the REFERENCE's precision: `--nn f16x3` =
 64 golden roots -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 one more
 leg is timed in the same run and reported as an extra key of the same JSON line: `secondary` = the bf16
 tower (reduced precision: NOT the headline); `--oversubscribe G2` adds a leg with G2 concurrent games (`oversubscribed`);
-`with_pass_value_reuse` is the same workload with the engine's pass-value reuse on (off in the headline).
+`with_evaluation_reuse` is the same workload with the engine's evaluation reuse on (off in the headline).
 """
 import argparse
 import ctypes
@@ -60,10 +60,10 @@ def parse():
                     help="N=1 only: a third leg with this many concurrent games (compacted leaf batch ~ whole workgroup "
                          "rounds); 0 (default) = skip: measured neutral, the launch time is proportional to the live rows")
     ap.add_argument("--oversubscribe-steps", type=int, default=3)
-    ap.add_argument("--reuse-pass-value", type=int, default=0,
-                    help="1 = the main leg runs with the engine's pass-value reuse (YY_FLAG_REUSE_PASS_VALUE); default 0: the "
-                         "evaluator is given every row the reference evaluates")
-    ap.add_argument("--reuse-steps", type=int, default=3, help="steps of the extra leg with pass-value reuse on (0 = skip)")
+    ap.add_argument("--reuse-evaluations", type=int, default=0,
+                    help="1 = the main leg runs with the engine's evaluation reuse (YY_FLAG_REUSE_PASS_VALUE | "
+                         "YY_FLAG_REUSE_TRANSPOSITIONS); default 0: the evaluator is given every row the reference evaluates")
+    ap.add_argument("--reuse-steps", type=int, default=6, help="steps of the extra leg with evaluation reuse on (0 = skip)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -380,11 +380,12 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
                          board_semantics=args.semantics, reference_quirks=args.quirks,
                          use_graph=not args.no_graph, seed=1000, device=dev,
                          first_game_index=rank, game_index_stride=world,
-                         reuse_pass_value=bool(args.reuse_pass_value if reuse is None else reuse))
+                         reuse_pass_value=bool(args.reuse_evaluations if reuse is None else reuse),
+                         reuse_transpositions=bool(args.reuse_evaluations if reuse is None else reuse))
     stagger_start(eng, 4242 + rank)
     leg = timed_region(eng, steps, warmup, rank, world, dist, cdev, args.sims,
                        capacity=example_capacity(games * world, world, eng.T))
-    leg["nn"], leg["reuse"] = nn, eng.reuse_pass_value
+    leg["nn"], leg["reuse"] = nn, eng.reuse_pass_value or eng.reuse_transpositions
     if with_roofline and rank == 0:
         leg["roofline"] = make_roofline(args, eng, games)
     eng.close()
@@ -467,7 +468,7 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
                                f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
                                f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
                    "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
-                   "pass_value_reuse": bool(main_leg.get("reuse", False)),
+                   "evaluation_reuse": bool(main_leg.get("reuse", False)),
                    "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
         "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
         **roof, **(extra or {}),
@@ -518,14 +519,15 @@ def main():
                 args.secondary_nn, "" if args.secondary_nn in FP32_GRADE else
                 ": REDUCED precision against the reference's float32 (not the headline; parity figures in "
                 "tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi)"))
-        if args.reuse_steps > 0 and not args.reuse_pass_value and args.semantics == "copied":
+        if args.reuse_steps > 0 and not args.reuse_evaluations and args.semantics == "copied":
             leg = run_leg(args, args.nn, args.games, args.reuse_steps, 1, rank, world, dist, cdev, False, reuse=True)
-            s = leg_summary(leg, "same workload and evaluator with the engine's pass-value reuse ON (the SelfPlayEngine default for this "
+            s = leg_summary(leg, "same workload and evaluator with the engine's evaluation reuse ON (the SelfPlayEngine default for this "
                                  "evaluator; OFF in the headline so that the evaluator sees the reference's rows one for one): a node "
-                                 "without legal moves is evaluated once instead of on every visit (ai/mcts.py:93-95); the games are the "
-                                 "same move for move (tests/test_gpu_selfplay.py::test_pass_value_reuse_plays_the_same_games)")
-            s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated; the skipped ones are not counted
-            extra["with_pass_value_reuse"] = s
+                                 "without legal moves is evaluated once instead of on every visit (ai/mcts.py:93-95), and a leaf whose "
+                                 "position an earlier node of the same search holds takes that node's priors and value (:385-397); the "
+                                 "games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
+            s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated; the reused ones are not counted
+            extra["with_evaluation_reuse"] = s
         over = max(args.oversubscribe, 0)
         if over > 0:
             leg = run_leg(args, args.nn, over, args.oversubscribe_steps, 1, rank, world, dist, cdev, False)

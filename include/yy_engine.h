@@ -52,6 +52,17 @@ extern "C" {
                               ::test_pass_value_reuse_*); counters[0] (evaluator rows) gets smaller.  Default off:
                               the evaluator call sequence is then the reference's, row for row. */
 
+#define YY_FLAG_REUSE_TRANSPOSITIONS 8u /* copied boards only.  Inside one search the same position is often reached by several
+                              move orders (and, late in a game, most leaves are such repeats); the reference evaluates each
+                              of them (ai/mcts.py:385-397), and a deterministic evaluator returns the same (policy, value)
+                              every time.  With this flag every search keeps a per-game position table (open addressing on
+                              a hash of the bitboards, verified against the node's stored board): a new leaf whose position
+                              an earlier node of the search already holds takes that node's priors and value instead of an
+                              evaluator row (needs_eval = 0, counters[7] += 1).  Within a search a position fixes the side
+                              to move (stones alternate and the tree never descends through a pass), and only the root's
+                              priors carry noise -- the root is never a source.  Same visit counts, value sums and pi
+                              (tests/test_gpu_mcts.py::test_pass_value_reuse_*).  Default off. */
+
 typedef void *yy_stream_t;
 
 const char *yy_last_error(void);
@@ -169,7 +180,7 @@ int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
  * NaN priors or a NaN value from the evaluator; such a game stops searching, and the flag is sticky: yy_mcts_begin
  * does not clear it, only this call does -- and
  * counters[8] = {evaluator rows requested, selection levels walked, children scanned during
- * selection, children created, terminal revisits, nodes created, pass values reused, 0} accumulated since create
+ * selection, children created, terminal revisits, nodes created, pass values reused, position-table hits} accumulated since create
  * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
 int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
 int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);

@@ -197,9 +197,9 @@ def test_bench_json_contract(tmp_path):
     assert tree["bound"] == "hbm" and "traffic_source" in tree and 0 < tree["eval_fraction"] <= 1
     # the launch as the timed steps issue it (compacted live rows), beside the dense one
     assert 0 < rf["live_rows"] <= 256 and rf["live_launch_ms"] > 0 and abs(rf["live_frac"] - rf["live_achieved"] / rf["peak"]) < 1e-9
-    # the headline leg gives the evaluator every row the reference evaluates; the engine's pass-value reuse is a labelled extra leg
-    assert d["config"]["pass_value_reuse"] is False
-    ru = d["with_pass_value_reuse"]
+    # the headline leg gives the evaluator every row the reference evaluates; the engine's evaluation reuse is a labelled extra leg
+    assert d["config"]["evaluation_reuse"] is False
+    ru = d["with_evaluation_reuse"]
     assert ru["nn"] == "f16x3" and ru["value"] > 0 and ru["evaluator_rows_per_s"] > 0 and ru["eval_fraction"] <= tree["eval_fraction"] + 0.02
 
 
@@ -224,7 +224,7 @@ def test_bench_under_the_distributed_launcher(nproc, backend):
     d = json.loads(lines[0])
     assert d["n_gpus"] == nproc and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f16x3"
     if nproc > 1:                                              # the CPU leg and the extra legs are N = 1 only
-        assert d["cpu_baseline"] is None and "secondary" not in d and "with_pass_value_reuse" not in d
+        assert d["cpu_baseline"] is None and "secondary" not in d and "with_evaluation_reuse" not in d
     assert f"episode-sharded x{nproc}" == d["config"]["parallelism"]
     # staggered starts: some slots are between games in a given move, most are searching
     assert 0.5 * 2 * 320 * nproc <= d["value"] * d["ms_per_step"] * 2 / 1e3 <= 2 * 320 * nproc

@@ -280,24 +280,29 @@ def _late_positions(E, G, R, C, max_ply, seed):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "split"])
-def test_pass_value_reuse_returns_the_same_search(pkg, fused):
-    """YY_FLAG_REUSE_PASS_VALUE (include/yy_engine.h): a childless non-terminal node -- the reference evaluates it again on
-    every visit, ai/mcts.py:93-95, 371-397 -- keeps the value of its first evaluation.  Late-game 8x8 positions (where such
-    nodes are common, pass ROOTS included): visit counts, root statistics and pi are identical to the plain search and to the
-    oracle (= the reference's evaluation sequence), the evaluator is asked for `reused_values` fewer rows, and those rows are
-    not flagged in needs_eval."""
+@pytest.mark.parametrize("shape,G,sims,max_ply", [((8, 8), 768, 200, 60), ((12, 12), 96, 150, 130), ((6, 6), 256, 120, 34)],
+                         ids=["8x8", "12x12", "6x6"])
+def test_evaluation_reuse_returns_the_same_search(pkg, fused, shape, G, sims, max_ply):
+    """YY_FLAG_REUSE_PASS_VALUE / YY_FLAG_REUSE_TRANSPOSITIONS (include/yy_engine.h).  The reference evaluates a childless
+    non-terminal node again on every visit (ai/mcts.py:93-95, 371-397) and every leaf whose position another node of the search
+    already holds (:385-397); the flags take those evaluations from the tree.  Positions from the opening to the end of the game
+    (pass ROOTS and finished games included; one, two and three bitboard words): visit counts, root statistics and pi are
+    identical to the plain search and to the oracle (= the reference's evaluation sequence), the evaluator is asked for exactly
+    `reused_values + transposition_hits` fewer rows, and needs_eval flags exactly the rows that are evaluated."""
     import torch
     from hash_eval import hash_eval_torch
     E = pkg.engine
-    G, R, C, sims = 768, 8, 8, 200
-    boards, players = _late_positions(E, G, R, C, 60, 9)
+    R, C = shape
+    boards, players = _late_positions(E, G, R, C, max_ply, 9)
     legal = E.valid_mask(boards, players).cpu().numpy()
     ended = E.game_ended(boards, players).cpu().numpy()
     pass_roots = (legal.sum(1) == 0) & (ended == 0)
-    assert pass_roots.sum() >= 3 and (ended != 0).sum() >= 3          # the batch holds pass roots and finished games too
+    if shape == (8, 8):
+        assert pass_roots.sum() >= 3 and (ended != 0).sum() >= 3          # the batch holds pass roots and finished games too
     res = {}
-    for reuse in (False, True):
-        m = E.BatchedMCTS(G, R, C, sims, reuse_pass_value=reuse)
+    for tag, kw in (("plain", {}), ("pass", dict(reuse_pass_value=True)),
+                    ("both", dict(reuse_pass_value=True, reuse_transpositions=True)), ("tt", dict(reuse_transpositions=True))):
+        m = E.BatchedMCTS(G, R, C, sims, **kw)
         rows = []
 
         def ev(planes, m=m, rows=rows):
@@ -306,25 +311,52 @@ def test_pass_value_reuse_returns_the_same_search(pkg, fused):
 
         counts = m.search(boards, players, ev, sims, fused=fused)
         visits, wsum = m.root_stats()
-        res[reuse] = (counts.cpu().numpy(), visits.cpu().numpy(), wsum.cpu().numpy(), m.root_policy().cpu().numpy(), m.status(), rows)
+        res[tag] = (counts.cpu().numpy(), visits.cpu().numpy(), wsum.cpu().numpy(), m.root_policy().cpu().numpy(), m.status(), rows)
         m.close()
-    (c0, n0, w0, p0, k0, r0), (c1, n1, w1, p1, k1, r1) = res[False], res[True]
-    assert np.array_equal(c0, c1) and np.array_equal(n0, n1) and np.array_equal(w0, w1) and np.array_equal(p0, p1)
-    assert k0["reused_values"] == 0 and k1["reused_values"] > 0.05 * k0["evals"]
-    assert k1["evals"] + k1["reused_values"] == k0["evals"]
-    assert k1["nodes"] == k0["nodes"] and k1["terminal_revisits"] == k0["terminal_revisits"]
-    assert sum(r1[1:]) == k1["evals"] and sum(r0[1:]) == k0["evals"]      # needs_eval flags exactly the rows that are evaluated (call 0 = the root call)
-    # (a pass root is evaluated by the root call of mcts.py:288 and by its first simulation, then never again)
+    c0, n0, w0, p0, k0, r0 = res["plain"]
+    assert k0["reused_values"] == 0 and k0["transposition_hits"] == 0 and sum(r0[1:]) == k0["evals"]
+    for tag in ("pass", "both", "tt"):
+        c1, n1, w1, p1, k1, r1 = res[tag]
+        assert np.array_equal(c0, c1) and np.array_equal(n0, n1) and np.array_equal(w0, w1) and np.array_equal(p0, p1), tag
+        assert k1["evals"] + k1["reused_values"] + k1["transposition_hits"] == k0["evals"], (tag, k0, k1)
+        assert k1["nodes"] == k0["nodes"] and k1["terminal_revisits"] == k0["terminal_revisits"] and k1["children_created"] == k0["children_created"]
+        assert sum(r1[1:]) == k1["evals"]                          # (call 0 = the root call, mcts.py:288)
+    assert res["pass"][4]["reused_values"] > 0 and res["pass"][4]["transposition_hits"] == 0
+    assert res["tt"][4]["reused_values"] == 0 and res["tt"][4]["transposition_hits"] > 0
+    both = res["both"][4]
+    assert both["transposition_hits"] > 0 and both["reused_values"] > 0
+    print("%dx%d, %d sims: evaluator rows %d plain, %d with pass values, %d with both (-%.1f %%)" % (
+        R, C, sims, k0["evals"], res["pass"][4]["evals"], both["evals"], 100 - 100.0 * both["evals"] / k0["evals"]))
     bh, ph = boards.cpu().numpy(), players.cpu().numpy()
+    c1 = res["both"][0]
     for g in list(np.flatnonzero(pass_roots)[:3]) + list(np.random.default_rng(3).choice(G, 24, replace=False)):
         r = O.search_hash(bh[g], int(ph[g]), sims, 1, 6, 4)
         assert np.array_equal(c1[g], r.counts), g
 
 
-def test_pass_value_reuse_needs_copied_boards(pkg):
-    with pytest.raises(pkg._lib.YYError) as ei:
-        pkg.engine.BatchedMCTS(4, 6, 6, 10, aliased=True, reuse_pass_value=True)
-    assert ei.value.code == -1
+def test_evaluation_reuse_with_a_small_position_table(pkg):
+    """The position table is sized from the node arena (at most half full); a probe sequence that finds neither the position
+    nor a free slot within 8 steps just evaluates the leaf.  A tiny arena (nodes_per_game) forces long probe runs: same results."""
+    import torch
+    from hash_eval import hash_eval_torch
+    E = pkg.engine
+    G, R, C, sims = 128, 8, 8, 30
+    boards, players = _late_positions(E, G, R, C, 50, 4)
+    out = []
+    for kw in ({}, dict(reuse_pass_value=True, reuse_transpositions=True, nodes_per_game=32)):
+        m = E.BatchedMCTS(G, R, C, sims, **kw)
+        c = m.search(boards, players, lambda p: hash_eval_torch(p, 6, 4), sims)
+        out.append((c.cpu().numpy(), m.root_stats()[1].cpu().numpy(), m.status()))
+        m.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[1][2]["transposition_hits"] > 0
+
+
+def test_evaluation_reuse_needs_copied_boards(pkg):
+    for kw in (dict(reuse_pass_value=True), dict(reuse_transpositions=True)):
+        with pytest.raises(pkg._lib.YYError) as ei:
+            pkg.engine.BatchedMCTS(4, 6, 6, 10, aliased=True, **kw)
+        assert ei.value.code == -1
 
 
 def test_search_with_rowcol_rule_vs_oracle(pkg):

@@ -369,11 +369,12 @@ def test_engine_is_reproducible_for_a_seed(pkg):
 
 
 @pytest.mark.parametrize("shape,G,games,sims", [((8, 8), 320, 320, 48), ((6, 6), 96, 128, 64)], ids=["8x8", "6x6"])
-def test_pass_value_reuse_plays_the_same_games(pkg, shape, G, games, sims):
+def test_evaluation_reuse_plays_the_same_games(pkg, shape, G, games, sims):
     """The engine's default with the split-f16 evaluator: a node without legal moves is evaluated once (YY_FLAG_REUSE_PASS_VALUE)
-    where the reference evaluates it on every visit (ai/mcts.py:93-95).  With the LIVE GPU evaluator, whole games (slot refill
+    and a leaf whose position the search already holds takes that node's evaluation (YY_FLAG_REUSE_TRANSPOSITIONS), where the
+    reference evaluates each of them (ai/mcts.py:93-95, 385-397).  With the LIVE GPU evaluator, whole games (slot refill
     included; the 8x8 batch is above the evaluator's register-ring threshold, so both tower kernels run): every state, pi, z of
-    every game is bit-identical with the option on and off, and the evaluator is asked for fewer rows."""
+    every game is bit-identical with the options on and off, and the evaluator is asked for fewer rows."""
     import torch
     game = pkg.YinYangGame(*shape)
     torch.manual_seed(0)
@@ -382,8 +383,9 @@ def test_pass_value_reuse_plays_the_same_games(pkg, shape, G, games, sims):
     assert ev.mode == "f16x3" and ev.row_independent
     runs, ctrs = [], []
     for reuse in (None, False):
-        eng = pkg.SelfPlayEngine(game, ev, num_simulations=sims, concurrent_games=G, seed=5, reuse_pass_value=reuse)
-        assert eng.reuse_pass_value == (reuse is None)
+        eng = pkg.SelfPlayEngine(game, ev, num_simulations=sims, concurrent_games=G, seed=5, reuse_pass_value=reuse,
+                                 reuse_transpositions=reuse)
+        assert eng.reuse_pass_value == (reuse is None) and eng.reuse_transpositions == (reuse is None)
         ex = eng.run(games)
         order = torch.argsort(ex["game_id"] * 1000 + ex["ply"])
         runs.append({k: v[order].cpu() for k, v in ex.items()})
@@ -392,10 +394,11 @@ def test_pass_value_reuse_plays_the_same_games(pkg, shape, G, games, sims):
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
     on, off = ctrs
-    assert off["reused_values"] == 0 and on["reused_values"] > 0
-    assert on["evals"] + on["reused_values"] == off["evals"] and on["nodes"] == off["nodes"]
-    print("pass-value reuse, %dx%d, %d games x %d sims: evaluator rows %d -> %d (-%.1f %%)" % (
-        *shape, games, sims, off["evals"], on["evals"], 100.0 * on["reused_values"] / off["evals"]))
+    assert off["reused_values"] == 0 and off["transposition_hits"] == 0 and on["reused_values"] > 0 and on["transposition_hits"] > 0
+    assert on["evals"] + on["reused_values"] + on["transposition_hits"] == off["evals"] and on["nodes"] == off["nodes"]
+    print("evaluation reuse, %dx%d, %d games x %d sims: evaluator rows %d -> %d (-%.1f %%: %d pass values, %d transpositions)" % (
+        *shape, games, sims, off["evals"], on["evals"], 100 - 100.0 * on["evals"] / off["evals"], on["reused_values"],
+        on["transposition_hits"]))
 
 
 # ---- per-game counter-based random streams (csrc/yy_selfplay.hip)

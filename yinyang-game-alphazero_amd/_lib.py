@@ -14,6 +14,7 @@ YY_E_ARENA = -6
 FLAG_ROWCOL = 1
 FLAG_ALIASED = 2
 FLAG_REUSE_PASS_VALUE = 4
+FLAG_REUSE_TRANSPOSITIONS = 8
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -441,10 +441,11 @@ extern "C" int yy_rules_mask_terminal_bb(const uint64_t *black, const uint64_t *
 }
 
 // =============================================================================== MCTS context
-enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5, K_REUSE = 6 };
+enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5, K_REUSE = 6, K_EXPAND_COPY = 7 };
 #define CHILD_NONE 0x00FFFFFFu
 #define NF_TERMINAL 1u
-#define NF_HASVALUE 2u   // pass node whose evaluator value is kept in the record's .z (YY_FLAG_REUSE_PASS_VALUE)
+#define NF_HASVALUE 2u   // childless node whose evaluator value (record .w) may be reused (YY_FLAG_REUSE_PASS_VALUE)
+#define TT_PROBES 8
 
 struct GameState {
     int32_t n_nodes, n_edges;
@@ -460,9 +461,11 @@ struct GameState {
     int8_t leaf_player;
     uint8_t leaf_terminal;
     uint8_t err_ever;       // sticky: set with err, survives yy_mcts_begin, cleared only by yy_mcts_status
+    int32_t leaf_src;       // K_EXPAND_COPY: the node with the same position whose evaluation is reused
+    int32_t leaf_tt_slot;   // K_EXPAND: free slot of the position table the new node goes into, or -1
     uint64_t leaf_board[2 * YY_MAX_NW];
     uint64_t leaf_mask[YY_MAX_NW];
-    uint64_t ctr[7];        // evals, levels, children scanned, children created, terminal revisits, nodes, reused pass values
+    uint64_t ctr[8];        // evals, levels, children scanned, children created, terminal revisits, nodes, reused pass values, position-table hits
 };
 
 struct yy_mcts {
@@ -472,6 +475,8 @@ struct yy_mcts {
     uint4 *edges, *nodes;
     uint64_t *nboard, *gboard;
     int32_t *path;
+    uint32_t *tt;           // [G, tt_cap] position table (node index + 1, 0 = empty), YY_FLAG_REUSE_TRANSPOSITIONS
+    int64_t tt_cap;
     GameState *state;
     float *sqrt_tab;
     uint64_t *scratch;      // [8] counters + overflow count
@@ -489,6 +494,8 @@ struct MctsDev {  // by-value kernel argument
     uint4 *edges, *nodes;
     uint64_t *nboard, *gboard;
     int32_t *path;
+    uint32_t *tt;
+    int32_t tt_cap;
     GameState *state;
     const float *sqrt_tab;
     int32_t sqrt_n;
@@ -510,6 +517,8 @@ static MctsDev make_dev(const yy_mcts *c) {
     d.nboard = c->nboard;
     d.gboard = c->gboard;
     d.path = c->path;
+    d.tt = c->tt;
+    d.tt_cap = (int32_t)c->tt_cap;
     d.state = c->state;
     d.sqrt_tab = c->sqrt_tab;
     d.sqrt_n = c->cfg.max_sims + 2;
@@ -558,6 +567,10 @@ template <int NW> __global__ void __launch_bounds__(64) k_begin(MctsDev d, const
         st->err = 0;
         st->leaf_kind = act ? K_ROOTINIT : K_NONE;
         d.nodes[(size_t)g * d.node_cap] = make_uint4(0u, node_pack(0, 0, players[g]), 0u, 0u);
+    }
+    if (d.tt) {   // the position table is per search (mcts.py:288 builds a new tree for every move)
+        uint4 *t = (uint4 *)(d.tt + (size_t)g * d.tt_cap);
+        for (int i = lane_id(); i < d.tt_cap / 4; i += 64) t[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     uint64_t *gbd = d.gboard + (size_t)g * 2 * NW;
     bb_store_lane0<NW>(gbd, black);
@@ -714,7 +727,35 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         bool term;
         float tv;
         leaf_rules<NW>(d.geo, gb, black, white, lplayer, mask, term, tv);
-        write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+        // YY_FLAG_REUSE_TRANSPOSITIONS: the evaluator is a function of the position alone, and within one search a position
+        // fixes the side to move (stones alternate; the tree never descends through a pass).  If an earlier node of this
+        // search holds the same position, its priors (edge records) and value (record .w) ARE this leaf's evaluation.
+        int src = -1, slot = -1;
+        if (d.tt && kind == K_EXPAND) {
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                h = (h ^ black.w[i]) * 0xFF51AFD7ED558CCDull;
+                h ^= h >> 32;
+                h = (h ^ white.w[i]) * 0xC4CEB9FE1A85EC53ull;
+                h ^= h >> 29;
+            }
+            const uint32_t *tt = d.tt + (size_t)g * d.tt_cap;
+            const uint32_t mask_c = (uint32_t)d.tt_cap - 1u;
+            uint32_t at = (uint32_t)h & mask_c;
+            for (int pr = 0; pr < TT_PROBES; pr++, at = (at + 1u) & mask_c) {
+                const uint32_t e = rfl((int)tt[at]);
+                if (e == 0u) { slot = (int)at; break; }
+                const uint64_t *nb = d.nboard + ((size_t)g * d.node_cap + (e - 1u)) * 2 * NW;
+                const BB<NW> ob = bb_uniform_load<NW>(nb), ow = bb_uniform_load<NW>(nb + NW);
+                bool same = true;
+#pragma unroll
+                for (int i = 0; i < NW; i++) same = same && ob.w[i] == black.w[i] && ow.w[i] == white.w[i];
+                if (same) { src = (int)(e - 1u); break; }
+            }
+        }
+        if (src >= 0) kind = K_EXPAND_COPY;
+        else write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NW; i++) {
@@ -725,8 +766,10 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             st->leaf_player = (int8_t)lplayer;
             st->leaf_terminal = term;
             st->leaf_tv = tv;
+            st->leaf_src = src;
+            st->leaf_tt_slot = slot;
         }
-        need = true;
+        need = src < 0;
     }
     if (lane == 0) {
         st->leaf_kind = (uint8_t)kind;
@@ -737,6 +780,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         if (need) st->ctr[0] += 1;
         if (kind == K_TERMINAL) st->ctr[4] += 1;
         if (kind == K_REUSE) st->ctr[6] += 1;
+        if (kind == K_EXPAND_COPY) st->ctr[7] += 1;
         if (needs_eval) needs_eval[g] = need;
     }
 }
@@ -760,9 +804,12 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         v = rflf(__uint_as_float(nodes[node].z));                                   // mcts.py:366
         v_is_py = true;
     } else if (kind == K_REUSE) {
-        v = rflf(__uint_as_float(nodes[node].z));                                   // the np.float32 the evaluator returned for this node
+        v = rflf(__uint_as_float(nodes[node].w));                                   // the np.float32 the evaluator returned for this node
     } else {
-        v = (kind == K_ROOTINIT) ? 0.0f : rflf(value[g]);
+        const bool copy = kind == K_EXPAND_COPY;                                    // evaluation taken from the node `src` (same position)
+        const int src = copy ? rfl(st->leaf_src) : 0;
+        const uint4 shdr = nodes[src];
+        v = (kind == K_ROOTINIT) ? 0.0f : copy ? rflf(__uint_as_float(shdr.w)) : rflf(value[g]);
         if (v != v) {   // a NaN from the evaluator must not enter the statistics: the game stops searching, the error is sticky
             if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
             return;
@@ -771,7 +818,7 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         const int lplayer = rfl((int)st->leaf_player);
         const bool term = rfl((int)st->leaf_terminal) != 0;
         int n_nodes = rfl(st->n_nodes), n_edges = rfl(st->n_edges);
-        if (kind == K_EXPAND) {
+        if (kind == K_EXPAND || copy) {
             if (n_nodes >= (int)d.node_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
             node = n_nodes++;
             if (lane == 0) {
@@ -792,10 +839,14 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         }
         if (term) {                                                                 // mcts.py:63-68
             if (lane == 0)
-                nodes[node] = make_uint4(0u, node_pack(0, NF_TERMINAL, lplayer), __float_as_uint(st->leaf_tv), 0u);
+                nodes[node] = make_uint4(0u, node_pack(0, NF_TERMINAL, lplayer), __float_as_uint(st->leaf_tv), __float_as_uint(v));
         } else {                                                                    // mcts.py:71-89
             const int k = bb_popc(mask);
-            if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
+            if (n_edges + k > (int)d.edge_cap || (copy && k != node_k(rfl(shdr.y)))) {
+                if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
+                return;
+            }
+            const int sfirst = rfl((int)shdr.x);
             const float keep = (float)(1.0 - d.eps);
             // a game whose noise row is all zero over its legal moves drew no noise (a Dirichlet draw
             // sums to 1): it keeps the raw priors, like add_exploration_noise=False (mcts.py:298)
@@ -816,7 +867,9 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
             for (int j = 0; j < NW; j++) {
                 const int cell = j * 64 + lane;
                 if ((mask.w[j] >> lane) & 1) {
-                    float p = policy[(size_t)g * A + cell];
+                    // a copy takes the j-th prior of the source node (same legal moves in the same ascending order)
+                    float p = copy ? __uint_as_float(edges[sfirst + (base - n_edges) + mbcnt(mask.w[j])].x)
+                                   : policy[(size_t)g * A + cell];
                     bad |= (p != p);
                     if (mix) {                                                      // mcts.py:310-312
                         const float kp = __fmul_rn(keep, p);
@@ -835,9 +888,8 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                 // a pass node keeps its value (not from the root call of mcts.py:288: that value is discarded and
                 // yy_mcts_expand_root is not given it -- a pass root keeps the value of its first simulation)
                 const bool hold = d.reuse && k == 0 && kind != K_ROOTINIT;
-                const float keepv = hold ? v : 0.0f;
-                nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, hold ? NF_HASVALUE : 0u, lplayer),
-                                         hold ? __float_as_uint(keepv) : 0u, 0u);
+                nodes[node] = make_uint4((uint32_t)n_edges, node_pack(k, hold ? NF_HASVALUE : 0u, lplayer), 0u,
+                                         __float_as_uint(v));                       // .w = the evaluator's value of this position
                 st->ctr[3] += (uint64_t)k;
             }
             n_edges += k;
@@ -845,6 +897,8 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         if (lane == 0) {
             st->n_nodes = n_nodes;
             st->n_edges = n_edges;
+            if (d.tt && kind == K_EXPAND && st->leaf_tt_slot >= 0)                  // later leaves with this position find it here
+                d.tt[(size_t)g * d.tt_cap + st->leaf_tt_slot] = (uint32_t)node + 1u;
         }
     }
     if (lane == 0) st->leaf_kind = K_NONE;
@@ -962,22 +1016,22 @@ template <int NW> __global__ void __launch_bounds__(64) k_get_boards(MctsDev d, 
     bb_to_board<NW>(boards + (size_t)g * d.geo.A, d.geo.A, b, w);
 }
 
-__global__ void k_status(MctsDev d, uint64_t *out /*[8]: 7 counters, overflow games*/) {
-    uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__global__ void k_status(MctsDev d, uint64_t *out /*[9]: 8 counters, overflow games*/) {
+    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < d.G; g += gridDim.x * blockDim.x) {
         GameState *st = d.state + g;
-        for (int i = 0; i < 7; i++) acc[i] += st->ctr[i];
-        acc[7] += (st->err || st->err_ever) ? 1 : 0;   // a failure in ANY search since the last status call
+        for (int i = 0; i < 8; i++) acc[i] += st->ctr[i];
+        acc[8] += (st->err || st->err_ever) ? 1 : 0;   // a failure in ANY search since the last status call
         st->err_ever = 0;
     }
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 9; i++)
         if (acc[i]) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
 }
 
 __global__ void k_reset_counters(MctsDev d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= d.G) return;
-    for (int i = 0; i < 7; i++) d.state[g].ctr[i] = 0;
+    for (int i = 0; i < 8; i++) d.state[g].ctr[i] = 0;
 }
 
 // ---------------------------------------------------------------------------------- host API
@@ -985,8 +1039,8 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     if (!cfg || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
     if (int e = check_geo(cfg->G, cfg->R, cfg->C)) return e;
     if (cfg->max_sims < 1) return set_err(YY_E_INVALID, "max_sims < 1%s%s");
-    if ((cfg->flags & YY_FLAG_REUSE_PASS_VALUE) && (cfg->flags & YY_FLAG_ALIASED))
-        return set_err(YY_E_INVALID, "YY_FLAG_REUSE_PASS_VALUE needs copied boards: with the aliased board a node's position changes between visits%s%s");
+    if ((cfg->flags & (YY_FLAG_REUSE_PASS_VALUE | YY_FLAG_REUSE_TRANSPOSITIONS)) && (cfg->flags & YY_FLAG_ALIASED))
+        return set_err(YY_E_INVALID, "YY_FLAG_REUSE_* need copied boards: with the aliased board a node's position changes between visits%s%s");
     yy_mcts *c = new yy_mcts();
     memset(c, 0, sizeof *c);
     c->cfg = *cfg;
@@ -1000,6 +1054,9 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     c->path_cap = (cfg->flags & YY_FLAG_ALIASED) ? (int64_t)cfg->max_sims + 2 : (int64_t)A + 2;
     const size_t G = (size_t)cfg->G;
     const bool copied = !(cfg->flags & YY_FLAG_ALIASED);
+    const bool tt_on = (cfg->flags & YY_FLAG_REUSE_TRANSPOSITIONS) != 0;
+    c->tt_cap = 64;
+    while (c->tt_cap < 2 * c->node_cap) c->tt_cap *= 2;      // at most half full: short probe sequences
     struct { void **p; size_t n; } allocs[] = {
         {(void **)&c->edges, G * c->edge_cap * sizeof(uint4)},
         {(void **)&c->nodes, G * c->node_cap * sizeof(uint4)},
@@ -1008,9 +1065,11 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
         {(void **)&c->path, G * c->path_cap * sizeof(int32_t)},
         {(void **)&c->state, G * sizeof(GameState)},
         {(void **)&c->sqrt_tab, (size_t)(cfg->max_sims + 2) * sizeof(float)},
-        {(void **)&c->scratch, 8 * sizeof(uint64_t)},
+        {(void **)&c->scratch, 9 * sizeof(uint64_t)},
+        {(void **)&c->tt, tt_on ? G * (size_t)c->tt_cap * sizeof(uint32_t) : 0},
     };
     for (auto &a : allocs) {
+        if (a.n == 0) continue;
         if (hipMalloc(a.p, a.n) != hipSuccess) {
             (void)hipGetLastError();
             yy_mcts_destroy(c);
@@ -1033,7 +1092,7 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
 
 extern "C" int yy_mcts_destroy(yy_mcts *c) {
     if (!c) return YY_OK;
-    void *ps[] = {c->edges, c->nodes, c->nboard, c->gboard, c->path, c->state, c->sqrt_tab, c->scratch};
+    void *ps[] = {c->edges, c->nodes, c->nboard, c->gboard, c->path, c->state, c->sqrt_tab, c->scratch, c->tt};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete c;
@@ -1136,17 +1195,16 @@ extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counter
     if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
     MctsDev d = make_dev(c);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(c->scratch, 0, 8 * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(c->scratch, 0, 9 * sizeof(uint64_t)));
     hipLaunchKernelGGL(k_status, dim3(64), dim3(256), 0, 0, d, c->scratch);
     HIP_TRY(hipGetLastError());
-    uint64_t h[8];
+    uint64_t h[9];
     HIP_TRY(hipMemcpy(h, c->scratch, sizeof h, hipMemcpyDeviceToHost));
     if (counters) {
-        for (int i = 0; i < 7; i++) counters[i] = h[i];
-        counters[7] = 0;
+        for (int i = 0; i < 8; i++) counters[i] = h[i];
     }
-    if (n_overflow) *n_overflow = (int32_t)h[7];
-    if (h[7]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
+    if (n_overflow) *n_overflow = (int32_t)h[8];
+    if (h[8]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
     return YY_OK;
 }
 
