@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--oversubscribe-steps", type=int, default=3)
     ap.add_argument("--reuse-evaluations", type=int, default=0,
                     help="1 = the main leg runs with the engine's evaluation reuse (YY_FLAG_REUSE_PASS_VALUE | "
-                         "YY_FLAG_REUSE_TRANSPOSITIONS); default 0: the evaluator is given every row the reference evaluates")
+                         "YY_FLAG_REUSE_TRANSPOSITIONS | YY_FLAG_KEEP_EVALUATIONS); default 0: the evaluator is given every row the reference evaluates")
     ap.add_argument("--reuse-steps", type=int, default=6, help="steps of the extra leg with evaluation reuse on (0 = skip)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
@@ -381,7 +381,8 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
                          use_graph=not args.no_graph, seed=1000, device=dev,
                          first_game_index=rank, game_index_stride=world,
                          reuse_pass_value=bool(args.reuse_evaluations if reuse is None else reuse),
-                         reuse_transpositions=bool(args.reuse_evaluations if reuse is None else reuse))
+                         reuse_transpositions=bool(args.reuse_evaluations if reuse is None else reuse),
+                         keep_evaluations=bool(args.reuse_evaluations if reuse is None else reuse))
     stagger_start(eng, 4242 + rank)
     leg = timed_region(eng, steps, warmup, rank, world, dist, cdev, args.sims,
                        capacity=example_capacity(games * world, world, eng.T))
@@ -524,8 +525,8 @@ def main():
             s = leg_summary(leg, "same workload and evaluator with the engine's evaluation reuse ON (the SelfPlayEngine default for this "
                                  "evaluator; OFF in the headline so that the evaluator sees the reference's rows one for one): a node "
                                  "without legal moves is evaluated once instead of on every visit (ai/mcts.py:93-95), and a leaf whose "
-                                 "position an earlier node of the same search holds takes that node's priors and value (:385-397); the "
-                                 "games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
+                                 "position this search or an earlier search of the same game has evaluated takes the cached policy row "
+                                 "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
             s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated; the reused ones are not counted
             extra["with_evaluation_reuse"] = s
         over = max(args.oversubscribe, 0)

@@ -52,16 +52,24 @@ extern "C" {
                               ::test_pass_value_reuse_*); counters[0] (evaluator rows) gets smaller.  Default off:
                               the evaluator call sequence is then the reference's, row for row. */
 
-#define YY_FLAG_REUSE_TRANSPOSITIONS 8u /* copied boards only.  Inside one search the same position is often reached by several
-                              move orders (and, late in a game, most leaves are such repeats); the reference evaluates each
-                              of them (ai/mcts.py:385-397), and a deterministic evaluator returns the same (policy, value)
-                              every time.  With this flag every search keeps a per-game position table (open addressing on
-                              a hash of the bitboards, verified against the node's stored board): a new leaf whose position
-                              an earlier node of the search already holds takes that node's priors and value instead of an
-                              evaluator row (needs_eval = 0, counters[7] += 1).  Within a search a position fixes the side
-                              to move (stones alternate and the tree never descends through a pass), and only the root's
-                              priors carry noise -- the root is never a source.  Same visit counts, value sums and pi
-                              (tests/test_gpu_mcts.py::test_pass_value_reuse_*).  Default off. */
+#define YY_FLAG_REUSE_TRANSPOSITIONS 8u /* evaluation cache, one search at a time.  The reference evaluates every leaf
+                              (ai/mcts.py:371-397), also when the position was evaluated before: another move order
+                              inside the same search, a pass node visited again.  A deterministic evaluator returns the
+                              same (policy, value) each time -- its input planes encode the board only, not the side to
+                              move (ai/neural_network.py:156-196).  With this flag every game keeps a table in HBM
+                              [position -> policy row f32[A], value], open addressing on a 64-bit mix of the bitboards,
+                              <= 8 probes, keys compared in full; a leaf whose position is in the table takes its
+                              evaluation from there instead of an evaluator row (needs_eval = 0, no planes written,
+                              counters[7] += 1).  Only entries written by the current search are used.  Same visit
+                              counts, value sums and pi (tests/test_gpu_mcts.py::test_evaluation_reuse_*).  Works with
+                              copied and aliased boards (the key is the position, not the node).  Default off: the
+                              evaluator's call sequence is then the reference's, row for row. */
+#define YY_FLAG_KEEP_EVALUATIONS 16u /* implies the table of YY_FLAG_REUSE_TRANSPOSITIONS and keeps its entries from one
+                              search to the next (the next move's search re-derives much of the subtree the game walked
+                              into: at 8x8 / 800 simulations about half of the rows that are new within a search were
+                              evaluated by an earlier search of the same game).  Entries are replaced oldest-game first,
+                              then positions that cannot recur (no more stones than the root).  REQUIRES that every
+                              search of the context uses the same evaluator: call yy_mcts_cache_clear when it changes. */
 
 typedef void *yy_stream_t;
 
@@ -180,10 +188,13 @@ int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
  * NaN priors or a NaN value from the evaluator; such a game stops searching, and the flag is sticky: yy_mcts_begin
  * does not clear it, only this call does -- and
  * counters[8] = {evaluator rows requested, selection levels walked, children scanned during
- * selection, children created, terminal revisits, nodes created, pass values reused, position-table hits} accumulated since create
+ * selection, children created, terminal revisits, nodes created, pass values reused, evaluation-cache hits} accumulated since create
  * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
 int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
 int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);
+/* Forget every cached evaluation (YY_FLAG_REUSE_TRANSPOSITIONS / YY_FLAG_KEEP_EVALUATIONS): to be called when the evaluator
+ * (the network) changes between two searches of one context.  Async on `stream`. */
+int yy_mcts_cache_clear(yy_mcts *ctx, yy_stream_t stream);
 
 /* ------------------------------------------------------------------ evaluator epilogue
  * Batched leaf evaluator fast path (the reference evaluates one board per call:

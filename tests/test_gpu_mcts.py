@@ -301,7 +301,9 @@ def test_evaluation_reuse_returns_the_same_search(pkg, fused, shape, G, sims, ma
         assert pass_roots.sum() >= 3 and (ended != 0).sum() >= 3          # the batch holds pass roots and finished games too
     res = {}
     for tag, kw in (("plain", {}), ("pass", dict(reuse_pass_value=True)),
-                    ("both", dict(reuse_pass_value=True, reuse_transpositions=True)), ("tt", dict(reuse_transpositions=True))):
+                    ("both", dict(reuse_pass_value=True, reuse_transpositions=True)), ("tt", dict(reuse_transpositions=True)),
+                    ("keep", dict(reuse_pass_value=True, reuse_transpositions=True, keep_evaluations=True)),
+                    ("keep2", dict(reuse_pass_value=True, reuse_transpositions=True, keep_evaluations=True))):
         m = E.BatchedMCTS(G, R, C, sims, **kw)
         rows = []
 
@@ -309,13 +311,16 @@ def test_evaluation_reuse_returns_the_same_search(pkg, fused, shape, G, sims, ma
             rows.append(int(m.needs_eval.sum()))
             return hash_eval_torch(planes, 6, 4)
 
+        if tag == "keep2":            # the same search again on a context that keeps its evaluations: every leaf is cached
+            m.search(boards, players, lambda p: hash_eval_torch(p, 6, 4), sims, fused=fused)
+            m.reset_counters()
         counts = m.search(boards, players, ev, sims, fused=fused)
         visits, wsum = m.root_stats()
         res[tag] = (counts.cpu().numpy(), visits.cpu().numpy(), wsum.cpu().numpy(), m.root_policy().cpu().numpy(), m.status(), rows)
         m.close()
     c0, n0, w0, p0, k0, r0 = res["plain"]
     assert k0["reused_values"] == 0 and k0["transposition_hits"] == 0 and sum(r0[1:]) == k0["evals"]
-    for tag in ("pass", "both", "tt"):
+    for tag in ("pass", "both", "tt", "keep", "keep2"):
         c1, n1, w1, p1, k1, r1 = res[tag]
         assert np.array_equal(c0, c1) and np.array_equal(n0, n1) and np.array_equal(w0, w1) and np.array_equal(p0, p1), tag
         assert k1["evals"] + k1["reused_values"] + k1["transposition_hits"] == k0["evals"], (tag, k0, k1)
@@ -325,6 +330,8 @@ def test_evaluation_reuse_returns_the_same_search(pkg, fused, shape, G, sims, ma
     assert res["tt"][4]["reused_values"] == 0 and res["tt"][4]["transposition_hits"] > 0
     both = res["both"][4]
     assert both["transposition_hits"] > 0 and both["reused_values"] > 0
+    assert res["keep"][4]["evals"] == both["evals"]                  # a fresh context: nothing to find from earlier searches
+    assert res["keep2"][4]["evals"] == 0                             # everything the search needs was evaluated by the first one
     print("%dx%d, %d sims: evaluator rows %d plain, %d with pass values, %d with both (-%.1f %%)" % (
         R, C, sims, k0["evals"], res["pass"][4]["evals"], both["evals"], 100 - 100.0 * both["evals"] / k0["evals"]))
     bh, ph = boards.cpu().numpy(), players.cpu().numpy()
@@ -334,29 +341,73 @@ def test_evaluation_reuse_returns_the_same_search(pkg, fused, shape, G, sims, ma
         assert np.array_equal(c1[g], r.counts), g
 
 
-def test_evaluation_reuse_with_a_small_position_table(pkg):
-    """The position table is sized from the node arena (at most half full); a probe sequence that finds neither the position
-    nor a free slot within 8 steps just evaluates the leaf.  A tiny arena (nodes_per_game) forces long probe runs: same results."""
+def test_evaluation_cache_replacement_keeps_results(pkg):
+    """A tiny cache (sized from nodes_per_game: 128 slots per game) across eight consecutive searches of advancing positions:
+    the table fills, entries of positions that cannot recur are replaced, then live ones; every search still returns what the
+    plain search returns, and later searches find positions of earlier ones."""
     import torch
     from hash_eval import hash_eval_torch
     E = pkg.engine
     G, R, C, sims = 128, 8, 8, 30
-    boards, players = _late_positions(E, G, R, C, 50, 4)
-    out = []
-    for kw in ({}, dict(reuse_pass_value=True, reuse_transpositions=True, nodes_per_game=32)):
-        m = E.BatchedMCTS(G, R, C, sims, **kw)
-        c = m.search(boards, players, lambda p: hash_eval_torch(p, 6, 4), sims)
-        out.append((c.cpu().numpy(), m.root_stats()[1].cpu().numpy(), m.status()))
+    boards, players = _late_positions(E, G, R, C, 40, 4)
+    ev = lambda p: hash_eval_torch(p, 6, 4)
+    plain = E.BatchedMCTS(G, R, C, sims)
+    cached = E.BatchedMCTS(G, R, C, sims, reuse_pass_value=True, reuse_transpositions=True, keep_evaluations=True, nodes_per_game=32)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    hits = []
+    for rnd in range(8):
+        c0 = plain.search(boards, players, ev, sims)
+        w0 = plain.root_stats()[1]
+        cached.reset_counters()
+        c1 = cached.search(boards, players, ev, sims)
+        assert torch.equal(c0, c1) and torch.equal(w0, cached.root_stats()[1]), rnd
+        hits.append(cached.status()["transposition_hits"])
+        mask = E.valid_mask(boards, players).float()
+        has = mask.sum(1) > 0
+        act = torch.multinomial(torch.where(has[:, None], mask, torch.ones_like(mask)), 1, generator=gen).reshape(-1).to(torch.int32)
+        E.step_(boards, players, torch.where(has, act, torch.full_like(act, -1)).contiguous())
+    plain.status()
+    plain.close()
+    cached.close()
+    assert min(hits[1:]) > 0, hits
+
+
+def test_evaluation_cache_with_aliased_boards_and_clear(pkg):
+    """The cache is keyed by the position, so it also serves the literal aliased-board search (the shared board a leaf is
+    evaluated on is looked up as it is at that moment); yy_mcts_cache_clear forgets everything (a new network)."""
+    import torch
+    from hash_eval import hash_eval_torch
+    E = pkg.engine
+    G, R, C, sims = 256, 8, 8, 120
+    boards, players = _late_positions(E, G, R, C, 56, 2)
+    ev = lambda p: hash_eval_torch(p, 6, 4)
+    out = {}
+    for tag, kw in (("plain", {}), ("cache", dict(reuse_transpositions=True, keep_evaluations=True))):
+        m = E.BatchedMCTS(G, R, C, sims, aliased=True, **kw)
+        b = boards.clone()
+        c = m.search(b, players, ev, sims)
+        out[tag] = (c.cpu().numpy(), m.root_stats()[1].cpu().numpy(), m.boards().cpu().numpy(), m.status())
+        if tag == "cache":
+            m.reset_counters()
+            m.search(boards.clone(), players, ev, sims)
+            again = m.status()
+            m.clear_evaluation_cache()
+            m.reset_counters()
+            m.search(boards.clone(), players, ev, sims)
+            cleared = m.status()
         m.close()
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    assert out[1][2]["transposition_hits"] > 0
+    for i in range(3):
+        assert np.array_equal(out["plain"][i], out["cache"][i]), i
+    k0, k1 = out["plain"][3], out["cache"][3]
+    assert k1["transposition_hits"] > 0 and k1["evals"] + k1["transposition_hits"] == k0["evals"]
+    assert again["evals"] == 0 and cleared["evals"] == k1["evals"]
 
 
-def test_evaluation_reuse_needs_copied_boards(pkg):
-    for kw in (dict(reuse_pass_value=True), dict(reuse_transpositions=True)):
-        with pytest.raises(pkg._lib.YYError) as ei:
-            pkg.engine.BatchedMCTS(4, 6, 6, 10, aliased=True, **kw)
-        assert ei.value.code == -1
+def test_pass_value_reuse_needs_copied_boards(pkg):
+    with pytest.raises(pkg._lib.YYError) as ei:      # the pass value lives in the NODE, whose position changes with aliased boards
+        pkg.engine.BatchedMCTS(4, 6, 6, 10, aliased=True, reuse_pass_value=True)
+    assert ei.value.code == -1
 
 
 def test_search_with_rowcol_rule_vs_oracle(pkg):

@@ -384,8 +384,8 @@ def test_evaluation_reuse_plays_the_same_games(pkg, shape, G, games, sims):
     runs, ctrs = [], []
     for reuse in (None, False):
         eng = pkg.SelfPlayEngine(game, ev, num_simulations=sims, concurrent_games=G, seed=5, reuse_pass_value=reuse,
-                                 reuse_transpositions=reuse)
-        assert eng.reuse_pass_value == (reuse is None) and eng.reuse_transpositions == (reuse is None)
+                                 reuse_transpositions=reuse, keep_evaluations=reuse)
+        assert eng.reuse_pass_value == eng.reuse_transpositions == eng.keep_evaluations == (reuse is None)
         ex = eng.run(games)
         order = torch.argsort(ex["game_id"] * 1000 + ex["ply"])
         runs.append({k: v[order].cpu() for k, v in ex.items()})

@@ -15,6 +15,7 @@ FLAG_ROWCOL = 1
 FLAG_ALIASED = 2
 FLAG_REUSE_PASS_VALUE = 4
 FLAG_REUSE_TRANSPOSITIONS = 8
+FLAG_KEEP_EVALUATIONS = 16
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -77,6 +78,7 @@ _SIGS = {
     "yy_mcts_get_boards": [_vp, _vp, _vp],
     "yy_mcts_status": [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)],
     "yy_mcts_reset_counters": [_vp, _vp],
+    "yy_mcts_cache_clear": [_vp, _vp],
     "yy_nn_bias_act_bf16": [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp],
     "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

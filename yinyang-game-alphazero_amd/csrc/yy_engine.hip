@@ -441,7 +441,7 @@ extern "C" int yy_rules_mask_terminal_bb(const uint64_t *black, const uint64_t *
 }
 
 // =============================================================================== MCTS context
-enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5, K_REUSE = 6, K_EXPAND_COPY = 7 };
+enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROOTPASS = 4, K_ROOTINIT = 5, K_REUSE = 6 };
 #define CHILD_NONE 0x00FFFFFFu
 #define NF_TERMINAL 1u
 #define NF_HASVALUE 2u   // childless node whose evaluator value (record .w) may be reused (YY_FLAG_REUSE_PASS_VALUE)
@@ -461,8 +461,10 @@ struct GameState {
     int8_t leaf_player;
     uint8_t leaf_terminal;
     uint8_t err_ever;       // sticky: set with err, survives yy_mcts_begin, cleared only by yy_mcts_status
-    int32_t leaf_src;       // K_EXPAND_COPY: the node with the same position whose evaluation is reused
-    int32_t leaf_tt_slot;   // K_EXPAND: free slot of the position table the new node goes into, or -1
+    int32_t leaf_src;       // >= 0: slot of the evaluation cache that holds this leaf's position (no evaluator row), else -1
+    int32_t leaf_ec_slot;   // leaf_src < 0: the cache slot this leaf's evaluation goes into
+    uint32_t ec_epoch;      // entries of other epochs are replaceable (see k_begin)
+    int32_t root_stones;    // stones on the root board: a cached position with no more stones cannot be a leaf again
     uint64_t leaf_board[2 * YY_MAX_NW];
     uint64_t leaf_mask[YY_MAX_NW];
     uint64_t ctr[8];        // evals, levels, children scanned, children created, terminal revisits, nodes, reused pass values, position-table hits
@@ -475,8 +477,12 @@ struct yy_mcts {
     uint4 *edges, *nodes;
     uint64_t *nboard, *gboard;
     int32_t *path;
-    uint32_t *tt;           // [G, tt_cap] position table (node index + 1, 0 = empty), YY_FLAG_REUSE_TRANSPOSITIONS
-    int64_t tt_cap;
+    // evaluation cache (YY_FLAG_REUSE_TRANSPOSITIONS / YY_FLAG_KEEP_EVALUATIONS): per game ec_cap slots, open addressing
+    uint32_t *ec_meta;      // [G, ec_cap]  epoch << 8 | stones, 0 = never used
+    uint64_t *ec_key;       // [G, ec_cap, 2*NW]  the position
+    float *ec_val;          // [G, ec_cap]  the evaluator's value
+    float *ec_pol;          // [G, ec_cap, A]  the evaluator's policy row
+    int64_t ec_cap;
     GameState *state;
     float *sqrt_tab;
     uint64_t *scratch;      // [8] counters + overflow count
@@ -494,8 +500,11 @@ struct MctsDev {  // by-value kernel argument
     uint4 *edges, *nodes;
     uint64_t *nboard, *gboard;
     int32_t *path;
-    uint32_t *tt;
-    int32_t tt_cap;
+    uint32_t *ec_meta;
+    uint64_t *ec_key;
+    float *ec_val, *ec_pol;
+    int32_t ec_cap;
+    uint32_t ec_keep;
     GameState *state;
     const float *sqrt_tab;
     int32_t sqrt_n;
@@ -517,8 +526,12 @@ static MctsDev make_dev(const yy_mcts *c) {
     d.nboard = c->nboard;
     d.gboard = c->gboard;
     d.path = c->path;
-    d.tt = c->tt;
-    d.tt_cap = (int32_t)c->tt_cap;
+    d.ec_meta = c->ec_meta;
+    d.ec_key = c->ec_key;
+    d.ec_val = c->ec_val;
+    d.ec_pol = c->ec_pol;
+    d.ec_cap = (int32_t)c->ec_cap;
+    d.ec_keep = (c->cfg.flags & YY_FLAG_KEEP_EVALUATIONS) ? 1u : 0u;
     d.state = c->state;
     d.sqrt_tab = c->sqrt_tab;
     d.sqrt_n = c->cfg.max_sims + 2;
@@ -568,9 +581,18 @@ template <int NW> __global__ void __launch_bounds__(64) k_begin(MctsDev d, const
         st->leaf_kind = act ? K_ROOTINIT : K_NONE;
         d.nodes[(size_t)g * d.node_cap] = make_uint4(0u, node_pack(0, 0, players[g]), 0u, 0u);
     }
-    if (d.tt) {   // the position table is per search (mcts.py:288 builds a new tree for every move)
-        uint4 *t = (uint4 *)(d.tt + (size_t)g * d.tt_cap);
-        for (int i = lane_id(); i < d.tt_cap / 4; i += 64) t[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (d.ec_meta && lane_id() == 0) {
+        // Entries of an older epoch are the first to be replaced.  Without YY_FLAG_KEEP_EVALUATIONS every search is its own
+        // epoch and only entries of the current one are looked at (reuse inside one search); with it the epoch changes when
+        // a game starts over from the empty board, so a game's searches share their evaluations.
+        int stones = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) stones += yy_popc64(black.w[i]) + yy_popc64(white.w[i]);
+        uint32_t ep = st->ec_epoch;
+        if (!d.ec_keep || stones == 0 || ep == 0u) ep = (ep + 1u) & 0xFFFFFFu;
+        if (ep == 0u) ep = 1u;
+        st->ec_epoch = ep;
+        st->root_stones = stones;
     }
     uint64_t *gbd = d.gboard + (size_t)g * 2 * NW;
     bb_store_lane0<NW>(gbd, black);
@@ -727,35 +749,49 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         bool term;
         float tv;
         leaf_rules<NW>(d.geo, gb, black, white, lplayer, mask, term, tv);
-        // YY_FLAG_REUSE_TRANSPOSITIONS: the evaluator is a function of the position alone, and within one search a position
-        // fixes the side to move (stones alternate; the tree never descends through a pass).  If an earlier node of this
-        // search holds the same position, its priors (edge records) and value (record .w) ARE this leaf's evaluation.
+        // Evaluation cache: the evaluator is a function of the position alone (the planes encode the board, not the side to
+        // move), so a position it has already seen -- another move order inside this search, a pass node visited again, or,
+        // with YY_FLAG_KEEP_EVALUATIONS, an earlier search of the same game -- needs no evaluator row: the cached policy row
+        // and value ARE this leaf's evaluation.  Keys are compared in full; the hash only picks the probe sequence.
         int src = -1, slot = -1;
-        if (d.tt && kind == K_EXPAND) {
+        if (d.ec_meta) {
+            // murmur3's 64-bit finalizer after every word: positions of one search differ in a few bits, and a single
+            // multiply leaves the low bits (the slot index) clustered -- measured: probe runs of 8 at 5 % load
             uint64_t h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
-            for (int i = 0; i < NW; i++) {
-                h = (h ^ black.w[i]) * 0xFF51AFD7ED558CCDull;
-                h ^= h >> 32;
-                h = (h ^ white.w[i]) * 0xC4CEB9FE1A85EC53ull;
-                h ^= h >> 29;
+            for (int i = 0; i < 2 * NW; i++) {
+                h ^= (i < NW) ? black.w[i] : white.w[i - NW];
+                h ^= h >> 33;
+                h *= 0xFF51AFD7ED558CCDull;
+                h ^= h >> 33;
+                h *= 0xC4CEB9FE1A85EC53ull;
+                h ^= h >> 33;
             }
-            const uint32_t *tt = d.tt + (size_t)g * d.tt_cap;
-            const uint32_t mask_c = (uint32_t)d.tt_cap - 1u;
+            const uint32_t *meta = d.ec_meta + (size_t)g * d.ec_cap;
+            const uint64_t *keys = d.ec_key + (size_t)g * d.ec_cap * 2 * NW;
+            const uint32_t mask_c = (uint32_t)d.ec_cap - 1u;
+            const uint32_t ep = (uint32_t)rfl((int)st->ec_epoch);
+            const int rstones = rfl(st->root_stones);
             uint32_t at = (uint32_t)h & mask_c;
+            const uint32_t at0 = at;
             for (int pr = 0; pr < TT_PROBES; pr++, at = (at + 1u) & mask_c) {
-                const uint32_t e = rfl((int)tt[at]);
-                if (e == 0u) { slot = (int)at; break; }
-                const uint64_t *nb = d.nboard + ((size_t)g * d.node_cap + (e - 1u)) * 2 * NW;
-                const BB<NW> ob = bb_uniform_load<NW>(nb), ow = bb_uniform_load<NW>(nb + NW);
-                bool same = true;
+                const uint32_t m = (uint32_t)rfl((int)meta[at]);
+                if (m == 0u) { if (slot < 0) slot = (int)at; break; }        // never used: the position is not in the table
+                const bool cur = (m >> 8) == ep;
+                if (cur || d.ec_keep) {
+                    const BB<NW> ob = bb_uniform_load<NW>(keys + (size_t)at * 2 * NW),
+                                 ow = bb_uniform_load<NW>(keys + (size_t)at * 2 * NW + NW);
+                    bool same = true;
 #pragma unroll
-                for (int i = 0; i < NW; i++) same = same && ob.w[i] == black.w[i] && ow.w[i] == white.w[i];
-                if (same) { src = (int)(e - 1u); break; }
+                    for (int i = 0; i < NW; i++) same = same && ob.w[i] == black.w[i] && ow.w[i] == white.w[i];
+                    if (same) { src = (int)at; break; }
+                }
+                // replaceable: another epoch, or a position that cannot come back (a leaf has more stones than the root)
+                if (slot < 0 && (!cur || (int)(m & 0xFFu) <= rstones)) slot = (int)at;
             }
+            if (slot < 0) slot = (int)at0;                                     // every probed entry is live: replace the first
         }
-        if (src >= 0) kind = K_EXPAND_COPY;
-        else write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+        if (src < 0) write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NW; i++) {
@@ -767,9 +803,10 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             st->leaf_terminal = term;
             st->leaf_tv = tv;
             st->leaf_src = src;
-            st->leaf_tt_slot = slot;
+            st->leaf_ec_slot = slot;
         }
         need = src < 0;
+        if (!need && lane == 0) st->ctr[7] += 1;
     }
     if (lane == 0) {
         st->leaf_kind = (uint8_t)kind;
@@ -780,7 +817,6 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         if (need) st->ctr[0] += 1;
         if (kind == K_TERMINAL) st->ctr[4] += 1;
         if (kind == K_REUSE) st->ctr[6] += 1;
-        if (kind == K_EXPAND_COPY) st->ctr[7] += 1;
         if (needs_eval) needs_eval[g] = need;
     }
 }
@@ -806,10 +842,10 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
     } else if (kind == K_REUSE) {
         v = rflf(__uint_as_float(nodes[node].w));                                   // the np.float32 the evaluator returned for this node
     } else {
-        const bool copy = kind == K_EXPAND_COPY;                                    // evaluation taken from the node `src` (same position)
-        const int src = copy ? rfl(st->leaf_src) : 0;
-        const uint4 shdr = nodes[src];
-        v = (kind == K_ROOTINIT) ? 0.0f : copy ? rflf(__uint_as_float(shdr.w)) : rflf(value[g]);
+        const int src = (d.ec_meta && kind != K_ROOTINIT) ? rfl(st->leaf_src) : -1;
+        const bool copy = src >= 0;                                                 // evaluation taken from cache slot `src`
+        const float *cpol = copy ? d.ec_pol + ((size_t)g * d.ec_cap + src) * d.geo.A : nullptr;
+        v = (kind == K_ROOTINIT) ? 0.0f : copy ? rflf(d.ec_val[(size_t)g * d.ec_cap + src]) : rflf(value[g]);
         if (v != v) {   // a NaN from the evaluator must not enter the statistics: the game stops searching, the error is sticky
             if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
             return;
@@ -818,7 +854,7 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         const int lplayer = rfl((int)st->leaf_player);
         const bool term = rfl((int)st->leaf_terminal) != 0;
         int n_nodes = rfl(st->n_nodes), n_edges = rfl(st->n_edges);
-        if (kind == K_EXPAND || copy) {
+        if (kind == K_EXPAND) {
             if (n_nodes >= (int)d.node_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
             node = n_nodes++;
             if (lane == 0) {
@@ -842,11 +878,7 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
                 nodes[node] = make_uint4(0u, node_pack(0, NF_TERMINAL, lplayer), __float_as_uint(st->leaf_tv), __float_as_uint(v));
         } else {                                                                    // mcts.py:71-89
             const int k = bb_popc(mask);
-            if (n_edges + k > (int)d.edge_cap || (copy && k != node_k(rfl(shdr.y)))) {
-                if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
-                return;
-            }
-            const int sfirst = rfl((int)shdr.x);
+            if (n_edges + k > (int)d.edge_cap) { if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; } return; }
             const float keep = (float)(1.0 - d.eps);
             // a game whose noise row is all zero over its legal moves drew no noise (a Dirichlet draw
             // sums to 1): it keeps the raw priors, like add_exploration_noise=False (mcts.py:298)
@@ -867,9 +899,7 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
             for (int j = 0; j < NW; j++) {
                 const int cell = j * 64 + lane;
                 if ((mask.w[j] >> lane) & 1) {
-                    // a copy takes the j-th prior of the source node (same legal moves in the same ascending order)
-                    float p = copy ? __uint_as_float(edges[sfirst + (base - n_edges) + mbcnt(mask.w[j])].x)
-                                   : policy[(size_t)g * A + cell];
+                    float p = copy ? cpol[cell] : policy[(size_t)g * A + cell];
                     bad |= (p != p);
                     if (mix) {                                                      // mcts.py:310-312
                         const float kp = __fmul_rn(keep, p);
@@ -897,8 +927,25 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
         if (lane == 0) {
             st->n_nodes = n_nodes;
             st->n_edges = n_edges;
-            if (d.tt && kind == K_EXPAND && st->leaf_tt_slot >= 0)                  // later leaves with this position find it here
-                d.tt[(size_t)g * d.tt_cap + st->leaf_tt_slot] = (uint32_t)node + 1u;
+        }
+        if (d.ec_meta && !copy && kind != K_ROOTINIT) {                            // a fresh evaluation goes into the cache
+            const int slot = rfl(st->leaf_ec_slot);
+            const size_t e = (size_t)g * d.ec_cap + slot;
+#pragma unroll
+            for (int j = 0; j < NW; j++) {
+                const int cell = j * 64 + lane;
+                if (cell < A) d.ec_pol[e * A + cell] = policy[(size_t)g * A + cell];
+            }
+            if (lane == 0) {
+                int stones = 0;
+#pragma unroll
+                for (int i = 0; i < 2 * NW; i++) {
+                    d.ec_key[e * 2 * NW + i] = st->leaf_board[i];
+                    stones += yy_popc64(st->leaf_board[i]);
+                }
+                d.ec_val[e] = v;
+                d.ec_meta[e] = (st->ec_epoch << 8) | (uint32_t)(stones & 0xFF);
+            }
         }
     }
     if (lane == 0) st->leaf_kind = K_NONE;
@@ -1039,8 +1086,8 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     if (!cfg || !out) return set_err(YY_E_INVALID, "null pointer%s%s");
     if (int e = check_geo(cfg->G, cfg->R, cfg->C)) return e;
     if (cfg->max_sims < 1) return set_err(YY_E_INVALID, "max_sims < 1%s%s");
-    if ((cfg->flags & (YY_FLAG_REUSE_PASS_VALUE | YY_FLAG_REUSE_TRANSPOSITIONS)) && (cfg->flags & YY_FLAG_ALIASED))
-        return set_err(YY_E_INVALID, "YY_FLAG_REUSE_* need copied boards: with the aliased board a node's position changes between visits%s%s");
+    if ((cfg->flags & YY_FLAG_REUSE_PASS_VALUE) && (cfg->flags & YY_FLAG_ALIASED))
+        return set_err(YY_E_INVALID, "YY_FLAG_REUSE_PASS_VALUE needs copied boards: with the aliased board a node's position changes between visits%s%s");
     yy_mcts *c = new yy_mcts();
     memset(c, 0, sizeof *c);
     c->cfg = *cfg;
@@ -1054,9 +1101,12 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     c->path_cap = (cfg->flags & YY_FLAG_ALIASED) ? (int64_t)cfg->max_sims + 2 : (int64_t)A + 2;
     const size_t G = (size_t)cfg->G;
     const bool copied = !(cfg->flags & YY_FLAG_ALIASED);
-    const bool tt_on = (cfg->flags & YY_FLAG_REUSE_TRANSPOSITIONS) != 0;
-    c->tt_cap = 64;
-    while (c->tt_cap < 2 * c->node_cap) c->tt_cap *= 2;      // at most half full: short probe sequences
+    const bool ec_on = (cfg->flags & (YY_FLAG_REUSE_TRANSPOSITIONS | YY_FLAG_KEEP_EVALUATIONS)) != 0;
+    // slots per game: 4x the node arena (the positions of several searches of a game stay useful), fewer when the
+    // policy rows of all games would exceed 48 GiB, never fewer than 2x the arena of one search
+    c->ec_cap = 64;
+    while (c->ec_cap < 4 * c->node_cap) c->ec_cap *= 2;
+    while (c->ec_cap > 2 * c->node_cap && (double)G * (double)c->ec_cap * A * 4.0 > 48.0 * 1073741824.0) c->ec_cap /= 2;
     struct { void **p; size_t n; } allocs[] = {
         {(void **)&c->edges, G * c->edge_cap * sizeof(uint4)},
         {(void **)&c->nodes, G * c->node_cap * sizeof(uint4)},
@@ -1066,7 +1116,10 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
         {(void **)&c->state, G * sizeof(GameState)},
         {(void **)&c->sqrt_tab, (size_t)(cfg->max_sims + 2) * sizeof(float)},
         {(void **)&c->scratch, 9 * sizeof(uint64_t)},
-        {(void **)&c->tt, tt_on ? G * (size_t)c->tt_cap * sizeof(uint32_t) : 0},
+        {(void **)&c->ec_meta, ec_on ? G * (size_t)c->ec_cap * sizeof(uint32_t) : 0},
+        {(void **)&c->ec_key, ec_on ? G * (size_t)c->ec_cap * 2 * NW * sizeof(uint64_t) : 0},
+        {(void **)&c->ec_val, ec_on ? G * (size_t)c->ec_cap * sizeof(float) : 0},
+        {(void **)&c->ec_pol, ec_on ? G * (size_t)c->ec_cap * A * sizeof(float) : 0},
     };
     for (auto &a : allocs) {
         if (a.n == 0) continue;
@@ -1082,6 +1135,7 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     for (int s = 0; s < cfg->max_sims + 2; s++) tab[s] = (float)sqrt((double)s);
     hipError_t e = hipMemset(c->state, 0, G * sizeof(GameState));
     if (e == hipSuccess) e = hipMemset(c->nodes, 0, G * c->node_cap * sizeof(uint4));
+    if (e == hipSuccess && c->ec_meta) e = hipMemset(c->ec_meta, 0, G * (size_t)c->ec_cap * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(c->sqrt_tab, tab, (size_t)(cfg->max_sims + 2) * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     delete[] tab;
@@ -1092,7 +1146,7 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
 
 extern "C" int yy_mcts_destroy(yy_mcts *c) {
     if (!c) return YY_OK;
-    void *ps[] = {c->edges, c->nodes, c->nboard, c->gboard, c->path, c->state, c->sqrt_tab, c->scratch, c->tt};
+    void *ps[] = {c->edges, c->nodes, c->nboard, c->gboard, c->path, c->state, c->sqrt_tab, c->scratch, c->ec_meta, c->ec_key, c->ec_val, c->ec_pol};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     delete c;
@@ -1205,6 +1259,12 @@ extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counter
     }
     if (n_overflow) *n_overflow = (int32_t)h[8];
     if (h[8]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_cache_clear(yy_mcts *c, yy_stream_t s) {
+    if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (c->ec_meta) HIP_TRY(hipMemsetAsync(c->ec_meta, 0, (size_t)c->cfg.G * (size_t)c->ec_cap * sizeof(uint32_t), (hipStream_t)s));
     return YY_OK;
 }
 

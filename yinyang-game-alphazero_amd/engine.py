@@ -9,7 +9,7 @@ import ctypes as ct
 import torch
 
 from . import _lib
-from ._lib import FLAG_ALIASED, FLAG_REUSE_PASS_VALUE, FLAG_REUSE_TRANSPOSITIONS, FLAG_ROWCOL, MctsConfig, check, lib
+from ._lib import FLAG_ALIASED, FLAG_REUSE_PASS_VALUE, FLAG_KEEP_EVALUATIONS, FLAG_REUSE_TRANSPOSITIONS, FLAG_ROWCOL, MctsConfig, check, lib
 
 
 def _stream():
@@ -347,21 +347,26 @@ class BatchedMCTS:
                 "transposition_hits")
 
     def __init__(self, G, R, C, max_sims, cpuct=1.0, aliased=False, rowcol=False, device=None,
-                 edges_per_game=0, nodes_per_game=0, reuse_pass_value=False, reuse_transpositions=False):
+                 edges_per_game=0, nodes_per_game=0, reuse_pass_value=False, reuse_transpositions=False,
+                 keep_evaluations=False):
         """reuse_pass_value (copied boards only): a childless non-terminal node keeps the value of its first
         evaluation instead of being evaluated again on every visit (YY_FLAG_REUSE_PASS_VALUE, include/yy_engine.h);
         needs a deterministic evaluator whose row results do not depend on the rest of the batch.
-        reuse_transpositions (copied boards only): a new leaf whose position an earlier node of the same search holds takes
-        that node's priors and value instead of an evaluator row (YY_FLAG_REUSE_TRANSPOSITIONS); same requirement."""
+        reuse_transpositions: a leaf whose position was already evaluated in this search takes the cached policy row and
+        value instead of an evaluator row (YY_FLAG_REUSE_TRANSPOSITIONS); same requirement.
+        keep_evaluations: the cache also serves the later searches of the context (YY_FLAG_KEEP_EVALUATIONS): every search
+        must then use the same evaluator -- call clear_evaluation_cache() when the network changes."""
         if not torch.cuda.is_available():
             raise _lib.YYError(-100, "BatchedMCTS needs a ROCm device: the hot path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.G, self.R, self.C, self.A = int(G), int(R), int(C), int(R) * int(C)
         self.max_sims, self.cpuct, self.aliased, self.rowcol = int(max_sims), float(cpuct), bool(aliased), bool(rowcol)
         self.reuse_pass_value, self.reuse_transpositions = bool(reuse_pass_value), bool(reuse_transpositions)
+        self.keep_evaluations = bool(keep_evaluations)
         cfg = MctsConfig(self.G, self.R, self.C, self.max_sims, self.cpuct,
                          _flags(rowcol, aliased) | (FLAG_REUSE_PASS_VALUE if reuse_pass_value else 0)
-                         | (FLAG_REUSE_TRANSPOSITIONS if reuse_transpositions else 0),
+                         | (FLAG_REUSE_TRANSPOSITIONS if reuse_transpositions else 0)
+                         | (FLAG_KEEP_EVALUATIONS if keep_evaluations else 0),
                          int(edges_per_game), int(nodes_per_game))
         h = ct.c_void_p()
         with torch.cuda.device(self.device):
@@ -454,6 +459,10 @@ class BatchedMCTS:
         with torch.cuda.device(self.device):
             check(lib().yy_mcts_status(self._h, ct.byref(n), ctr))
         return dict(zip(self.COUNTERS, [int(x) for x in ctr[:8]]))
+
+    def clear_evaluation_cache(self):
+        with torch.cuda.device(self.device):
+            check(lib().yy_mcts_cache_clear(self._h, _stream()))
 
     def reset_counters(self):
         with torch.cuda.device(self.device):

@@ -119,13 +119,15 @@ class SelfPlayEngine:
                  dirichlet_alpha=0.3, dirichlet_epsilon=0.25, temperature_threshold=10,
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
                  device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None,
-                 reuse_pass_value=None, reuse_transpositions=None):
-        """reuse_pass_value / reuse_transpositions: None = on when the boards are copied and the evaluator declares
-        `row_independent` (the split-f16 evaluator does).  The reference evaluates a node without legal moves again on every
-        visit (ai/mcts.py:93-95, 371-397) and every leaf whose position another node of the same search already holds
-        (:385-397), and gets the same numbers each time; with these options the search takes them from the tree instead
-        (YY_FLAG_REUSE_PASS_VALUE, YY_FLAG_REUSE_TRANSPOSITIONS in include/yy_engine.h).  The games played are the same, move for
-        move; the evaluator sees fewer rows (a third fewer over an 8x8 game, most of them late in the game)."""
+                 reuse_pass_value=None, reuse_transpositions=None, keep_evaluations=None):
+        """reuse_pass_value / reuse_transpositions / keep_evaluations: None = on when the boards are copied and the evaluator
+        declares `row_independent` (the split-f16 evaluator does).  The reference asks the network for every leaf: a node
+        without legal moves again on every visit (ai/mcts.py:93-95, 371-397), a position another move order of the same search
+        already reached (:385-397), a position the previous move's search evaluated -- and gets the same numbers each time.
+        With these options the search takes them from the tree / from a per-game evaluation cache in HBM instead
+        (YY_FLAG_REUSE_PASS_VALUE, YY_FLAG_REUSE_TRANSPOSITIONS, YY_FLAG_KEEP_EVALUATIONS in include/yy_engine.h).  The games
+        played are the same, move for move; the evaluator sees a fraction of the rows.  The engine owns ONE evaluator for its
+        lifetime, which is what keep_evaluations needs."""
         assert board_semantics in ("aliased", "copied")
         self.game = game
         self.R, self.C = game.getBoardSize()
@@ -143,10 +145,13 @@ class SelfPlayEngine:
             reuse_pass_value = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
         if reuse_transpositions is None:
             reuse_transpositions = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
+        if keep_evaluations is None:
+            keep_evaluations = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
         self.reuse_pass_value, self.reuse_transpositions = bool(reuse_pass_value), bool(reuse_transpositions)
+        self.keep_evaluations = bool(keep_evaluations)
         self.ctx = engine.BatchedMCTS(self.G, self.R, self.C, self.sims, cpuct=cpuct, aliased=self.aliased,
                                       rowcol=self.rowcol, device=self.device, reuse_pass_value=self.reuse_pass_value,
-                                      reuse_transpositions=self.reuse_transpositions)
+                                      reuse_transpositions=self.reuse_transpositions, keep_evaluations=self.keep_evaluations)
         self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
         self.seed = int(seed)                      # key of the per-game counter streams (csrc/yy_selfplay.hip)
         self.n_alive = 0                           # live games, tracked on the host (no device read needed)
