@@ -357,13 +357,14 @@ def timed_region(eng, steps, warmup, rank, world, dist, cdev, sims, capacity=Non
     if on_gpu:
         torch.cuda.synchronize()
     gather_s = time.perf_counter() - tg0
-    tot = torch.tensor([float(positions), float(counters["evals"]), dt], dtype=torch.float64, device=cdev)
+    served = counters.get("reused_values", 0) + counters.get("transposition_hits", 0)      # expansions that needed no evaluator row
+    tot = torch.tensor([float(positions), float(counters["evals"]), dt, float(served)], dtype=torch.float64, device=cdev)
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dt = float(mx[2])
-    return dict(games=eng.G, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), gather_s=gather_s,
+    return dict(games=eng.G, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), served=float(tot[3]), gather_s=gather_s,
                 examples=int(ex_all["states"].shape[0]), sims_total=steps * sims * eng.G * world,
                 eval_fraction=counters["evals"] / max(steps * sims * eng.G, 1))
 
@@ -527,7 +528,9 @@ def main():
                                  "without legal moves is evaluated once instead of on every visit (ai/mcts.py:93-95), and a leaf whose "
                                  "position this search or an earlier search of the same game has evaluated takes the cached policy row "
                                  "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
-            s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated; the reused ones are not counted
+            s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated
+            # tree nodes expanded (Node.expand calls of the reference, mcts.py:397): by an evaluator row or from the cache
+            s["node_expansions_per_s"] = (leg["evals"] + leg["served"]) / leg["dt"]
             extra["with_evaluation_reuse"] = s
         over = max(args.oversubscribe, 0)
         if over > 0:
