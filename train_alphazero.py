@@ -44,6 +44,9 @@ def parse_args(argv=None):
                    help="evaluator: auto = float32-accurate (f16x3 split-f16 tower where the kernels cover the shape, else the fp32 module; the "
                         "reference evaluates in float32); bf16 = reduced-precision fast tower; fp32t exact-f32 tower; bf16x3 split-bf16")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--evaluation-reuse", choices=["auto", "off"], default="auto",
+                   help="auto: the network is asked once per position of a game (pass values + per-game evaluation cache; "
+                        "identical games); off: once per leaf, like the reference")
     p.add_argument("--reference-format", action="store_true",
                    help="self-play: also store the reference's pickled board objects so its own training pipeline reads the file")
     p.add_argument("--arena-games", type=int, default=40)
@@ -93,7 +96,8 @@ def main(argv=None):
                                        concurrent_games=args.concurrent_games, board_semantics=args.board_semantics,
                                        reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed,
                                        num_channels=args.channels, num_res_blocks=args.blocks,
-                                       reference_format=args.reference_format)
+                                       reference_format=args.reference_format,
+                                       evaluation_reuse=None if args.evaluation_reuse == "auto" else False)
     if rank == 0:
         st = pkg.generate_self_play_data.last_stats
         st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])

@@ -521,7 +521,10 @@ class SelfPlayManager:
     def __init__(self, game, model_path, num_workers=1, num_simulations=800, games_per_worker=1,
                  temperature_threshold=10, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0,
                  mcts_parallel=1, concurrent_games=4096, board_semantics="copied", reference_quirks=False,
-                 nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10):
+                 nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10, evaluation_reuse=None):
+        """evaluation_reuse: None = the engine's default (on for copied boards with the float32-accurate evaluator: pass values +
+        per-game evaluation cache, SelfPlayEngine); False = the network is asked for every leaf like the reference."""
+        self.evaluation_reuse = evaluation_reuse
         self.game, self.model_path = game, model_path
         self.num_workers, self.games_per_worker = num_workers, games_per_worker
         self.num_simulations, self.temperature_threshold = num_simulations, temperature_threshold
@@ -547,7 +550,9 @@ class SelfPlayManager:
                              dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                              temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
                              reference_quirks=self.reference_quirks, seed=1000 + self.seed,   # key of the per-game streams: the same on every rank
-                             first_game_index=first, game_index_stride=stride, device=dev)
+                             first_game_index=first, game_index_stride=stride, device=dev,
+                             reuse_pass_value=self.evaluation_reuse, reuse_transpositions=self.evaluation_reuse,
+                             keep_evaluations=self.evaluation_reuse)
         t0 = time.perf_counter()
         ex = eng.run(mine) if mine > 0 else eng.collect()
         torch.cuda.synchronize(dev)
