@@ -20,3 +20,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE"; do
     timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex "k_mcts" --output-format csv -d "$O/pmc_mcts_$pass" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-graph --no-cpu-baseline --secondary-nn none --reuse-steps 0 > "$O/pmc_mcts_$pass.log" 2>&1 || exit 1
 done
 echo profiles done
+# the other board sizes of the float32-accurate tower (BASELINE configs 1 and 4): kernel-trace summary of the dense 4096-board launch
+for RR in 6 12; do
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/tower_$RR" -- python3 "$PY" 4096 10 r $RR > "$O/tower_$RR.log" 2>&1 || exit 1
+done
+echo board sizes done
