@@ -1123,10 +1123,14 @@ extern "C" int yy_mcts_create(const yy_mcts_config *cfg, yy_mcts **out) {
     };
     for (auto &a : allocs) {
         if (a.n == 0) continue;
-        if (hipMalloc(a.p, a.n) != hipSuccess) {
+        const hipError_t me = hipMalloc(a.p, a.n);
+        if (me != hipSuccess) {
             (void)hipGetLastError();
+            char what[96];
+            snprintf(what, sizeof what, " (%zu bytes after %llu allocated)", a.n, (unsigned long long)c->bytes);
+            *a.p = nullptr;
             yy_mcts_destroy(c);
-            return set_err(YY_E_NOMEM, "hipMalloc failed%s%s");
+            return set_err(YY_E_NOMEM, "hipMalloc failed: %s%s", hipGetErrorString(me), what);
         }
         c->bytes += a.n;
     }
