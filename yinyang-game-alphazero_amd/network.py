@@ -358,6 +358,8 @@ class BatchedEvaluator:
             self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
             self.fc2_w, self.fc2_b = f32(net.value_fc2.weight.reshape(-1)), f32(net.value_fc2.bias.reshape(1))
             self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
+            self.supports_static = True          # __call__(..., static=True): results in buffers kept per batch size
+            self._static = {}
             self.use_h3r = True
             self.tower = False
             # a row's (policy, value) is a function of that row's planes alone, bit for bit: the tower computes each board in a
@@ -438,21 +440,34 @@ class BatchedEvaluator:
         return engine.bias_act_(y, b, residual, relu=True)
 
     @torch.no_grad()
-    def __call__(self, planes, needs_eval=None):
+    def __call__(self, planes, needs_eval=None, static=False):
         """needs_eval (uint8 [G], modes with `supports_compaction` only): evaluate just the flagged rows -- the tower launch
-        gathers them, the other rows of the returned (policy, value) hold zeros and must not be read."""
+        gathers them, the other rows of the returned (policy, value) must not be read.
+        static (f16x3): write the row list and the results into buffers the evaluator keeps per batch size instead of fresh
+        zero-filled tensors (four fill kernels per call less); the returned tensors are overwritten by the next call."""
         if self.mode == "f16x3":
             from . import engine
-            rows = n = None
+            rows = n = pol = val = None
+            if static:
+                G = planes.shape[0]
+                buf = self._static.get(G)
+                if buf is None:
+                    dev = planes.device
+                    buf = self._static[G] = (torch.zeros(G, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                                             torch.zeros((G, self.pfc_b.shape[0]), dtype=torch.float32, device=dev),
+                                             torch.zeros(G, dtype=torch.float32, device=dev))
+                rows, n, pol, val = buf
             if needs_eval is not None:
-                rows, n = engine.compact_rows(needs_eval)
+                rows, n = engine.compact_rows(needs_eval, rows, n)
+            else:
+                rows = n = None
             if planes.shape[0] > self.h3r_min_rows and self.use_h3r:
                 feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, self.h3_exps, rows, n)
             else:
                 feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, self.h3_exps, rows, n)   # [G, 2, 32*cells] f32
             logits = torch.addmm(self.pfc_b, feats[:, 0], self.pfc_wt)                                    # [G, A]
             hidden = torch.addmm(self.vfc1_b, feats[:, 1], self.vfc1_wt)                                  # [G, 256]
-            return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n)
+            return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n, pol, val)
         if needs_eval is not None:
             raise ValueError(f"evaluator mode {self.mode} does not take needs_eval")
         if self.mode == "fp32":

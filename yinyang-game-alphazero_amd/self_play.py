@@ -62,6 +62,8 @@ class LockstepSearch:
         kw = {}
         if compact and getattr(self.evaluator, "supports_compaction", False):
             kw["needs_eval"] = ctx.needs_eval if rows >= ctx.G else ctx.needs_eval[:rows]
+        if getattr(self.evaluator, "supports_static", False):
+            kw["static"] = True                    # the results are consumed by the tree kernel before the next call
         if rows >= ctx.G:
             return self.evaluator(ctx.planes, **kw)
         policy, value = self.evaluator(ctx.planes[:rows], **kw)
