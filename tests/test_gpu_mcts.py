@@ -50,12 +50,13 @@ class HostHashEvaluator:
         return torch.from_numpy(pol).cuda(), torch.from_numpy(val).cuda()
 
 
-def _run_group(pkg, z, idx, fused):
+def _run_group(pkg, z, idx, fused, reuse=False):
     import torch
     R, C = z["root_board"].shape[1:]
     sims, copied = int(z["sims"][idx[0]]), int(z["copied"][idx[0]])
     G = len(idx)
-    m = pkg.engine.BatchedMCTS(G, R, C, sims, cpuct=1.0, aliased=not copied)
+    kw = dict(reuse_pass_value=bool(copied), reuse_transpositions=True, keep_evaluations=True) if reuse else {}
+    m = pkg.engine.BatchedMCTS(G, R, C, sims, cpuct=1.0, aliased=not copied, **kw)
     ev = HostHashEvaluator(z["pbits"][idx], z["vbits"][idx], m.needs_eval)
     boards = torch.from_numpy(z["root_board"][idx]).cuda()
     players = torch.from_numpy(z["root_player"][idx]).cuda()
@@ -80,11 +81,28 @@ def _run_group(pkg, z, idx, fused):
         assert float(wsum[j]) == float(z["root_w"][i]), tag
         assert np.array_equal(pi[j].cpu().numpy(), z["pi"][i]), tag
         assert np.array_equal(fb[j].cpu().numpy(), z["final_board"][i]), tag
+        if reuse:       # the evaluator is asked for a subsequence of the reference's leaves: every position once
+            assert len(ev.logs[j]) <= int(z["n_evals"][i]), tag
+            assert len({a.tobytes() for a in ev.logs[j]}) == len(ev.logs[j]), tag
+            continue
         assert len(ev.logs[j]) == int(z["n_evals"][i]), tag
         nl = int(z["n_leaves"][i])
         if nl:
             assert np.array_equal(np.stack(ev.logs[j]), z["leaves"][i, :nl]), tag
     m.close()
+
+
+@pytest.mark.parametrize("path", SEARCH, ids=[os.path.basename(p) for p in SEARCH])
+def test_search_golden_with_evaluation_reuse(pkg, path):
+    """The reference's own results (G3 fixtures: visit counts, float32 value sums, priors, pi, mutated boards; copied and
+    aliased boards, with and without noise, every geometry) with the evaluation reuse ON: pass values (copied boards) and the
+    evaluation cache.  Nothing changes but the rows the evaluator is asked for -- no position twice."""
+    z = np.load(path)
+    groups = {}
+    for i in range(z["counts"].shape[0]):
+        groups.setdefault((int(z["sims"][i]), int(z["copied"][i]), int(z["has_noise"][i])), []).append(i)
+    for key, idx in sorted(groups.items()):
+        _run_group(pkg, z, np.asarray(idx), True, reuse=True)
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_step", "select+expand"])
@@ -494,6 +512,41 @@ def test_live_gpu_evaluator_search_vs_reference_pi(pkg, mode):
     assert same.mean() >= frac, rec
     if bpi is not None:
         assert dpi.max() <= bpi and dv.max() <= bv, rec
+
+
+def test_live_gpu_evaluator_with_evaluation_reuse_vs_reference_pi(pkg):
+    """The 64 recorded 800-simulation searches of the reference (search_net800_8x8: both board semantics, with and without
+    root noise) with the LIVE split-f16 evaluator AND the evaluation reuse on: the reference's visit counts on every root,
+    pi / root value within 1e-5, while the evaluator is asked for each position once."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "search_net800_8x8.npz"))
+    torch.manual_seed(0)
+    game = pkg.YinYangGame(8, 8)
+    ev = pkg.BatchedEvaluator(pkg.YinYangNeuralNetwork(game).cuda().eval(), "f16x3")
+    rows_plain = rows_reuse = 0
+    for copied in (0, 1):
+        for has_noise in (0, 1):
+            idx = np.flatnonzero((z["copied"] == copied) & (z["has_noise"] == has_noise))
+            boards = torch.from_numpy(z["root_board"][idx]).cuda()
+            players = torch.ones(len(idx), dtype=torch.int8, device="cuda")
+            noise = torch.from_numpy(z["noise"][idx]).cuda() if has_noise else None
+            for reuse in (False, True):
+                mc = pkg.MCTS(game, ev, num_simulations=800, board_semantics="copied" if copied else "aliased", evaluation_reuse=reuse)
+                pi, ctx = mc.search_batch(boards.clone(), players, noise=noise)
+                counts = ctx.root_counts().cpu().numpy()
+                _, wsum = ctx.root_stats()
+                k = ctx.status()
+                assert np.array_equal(counts, z["counts"][idx]), (copied, has_noise, reuse)
+                assert np.abs(pi.cpu().numpy() - z["pi"][idx]).max() <= 1e-5
+                assert (np.abs(wsum.cpu().numpy() - z["root_w"][idx]) / 800.0).max() <= 1e-5
+                if reuse:
+                    rows_reuse += k["evals"]
+                    assert k["transposition_hits"] > 0
+                else:
+                    rows_plain += k["evals"]
+                mc.close()
+    print("64 reference roots x 800 sims: evaluator rows %d plain, %d with evaluation reuse" % (rows_plain, rows_reuse))
+    assert rows_reuse < rows_plain
 
 
 def test_nan_from_the_evaluator_is_a_sticky_error(pkg):

@@ -133,9 +133,12 @@ class _HostPredictEvaluator:
 class MCTS:
     def __init__(self, game, neural_net, num_simulations=800, cpuct=1.0, temperature=1.0, num_threads=1,
                  dirichlet_noise=True, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, verbose=1,
-                 board_semantics="aliased", device=None):
+                 board_semantics="aliased", device=None, evaluation_reuse=False):
         """board_semantics: "aliased" = literal reference (the search mutates the caller's board);
         "copied" = every node owns its board (what the reference's own tests assume).
+        evaluation_reuse (not in the reference; default off = its evaluator call sequence): a position is evaluated once per
+        search (pass values with copied boards + the evaluation cache, include/yy_engine.h YY_FLAG_REUSE_*); same results, fewer
+        evaluator rows; needs a deterministic network whose row results do not depend on the rest of the batch.
         num_threads is accepted for signature compatibility; simulations of one search are always
         sequential (the reference's thread pool is an unsynchronised race)."""
         assert board_semantics in ("aliased", "copied")
@@ -144,6 +147,7 @@ class MCTS:
         self.num_threads = max(1, num_threads)
         self.use_dirichlet, self.dirichlet_alpha, self.dirichlet_epsilon = dirichlet_noise, dirichlet_alpha, dirichlet_epsilon
         self.board_semantics = board_semantics
+        self.evaluation_reuse = bool(evaluation_reuse)
         self.R, self.C = game.getBoardSize()
         self.A = game.getActionSize()
         self.rowcol = bool(getattr(game, "rowcol_rule", False))
@@ -158,7 +162,9 @@ class MCTS:
                 ctx.close()
             ctx = engine.BatchedMCTS(G, self.R, self.C, self.num_simulations, cpuct=self.cpuct,
                                      aliased=(self.board_semantics == "aliased"), rowcol=self.rowcol,
-                                     device=self.device)
+                                     device=self.device,
+                                     reuse_pass_value=self.evaluation_reuse and self.board_semantics == "copied",
+                                     reuse_transpositions=self.evaluation_reuse)
             self._ctx[G] = ctx
         return ctx
 
