@@ -532,6 +532,7 @@ def main():
             # tree nodes expanded (Node.expand calls of the reference, mcts.py:397): by an evaluator row or from the cache
             s["node_expansions_per_s"] = (leg["evals"] + leg["served"]) / leg["dt"]
             extra["with_evaluation_reuse"] = s
+            extra["value_with_evaluation_reuse"] = s["value"]          # positions/s of the engine's default configuration
         over = max(args.oversubscribe, 0)
         if over > 0:
             leg = run_leg(args, args.nn, over, args.oversubscribe_steps, 1, rank, world, dist, cdev, False)
