@@ -164,6 +164,42 @@ def test_cli_self_play_config1(tmp_path):
             assert np.array_equal(a[k], b[k]), k          # same seed, same model -> the same file, bit for bit
 
 
+def test_cli_self_play_two_ranks_equals_one_rank(tmp_path):
+    """`train_alphazero.py --mode self-play` under the distributed launcher with two ranks (sharing this box's GPU, collectives
+    over gloo) against the single-process run: rank r plays games r, r+2, ..., ONE exchange collects the examples, rank 0
+    writes the file behind a barrier -- and the file holds the SAME examples (a game's noise and moves are keyed by its global
+    index, not by the rank or the slot it ran in): states, pi, z, game ids, plies, row for row after sorting."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir = tmp_path / "models"
+    os.makedirs(mdir)
+    torch.manual_seed(0)
+    pkg.YinYangNeuralNetwork(pkg.YinYangGame(6, 6), 128, 2).save_model(str(mdir / "best_model.pth.tar"))
+    base = [os.path.join(root, "train_alphazero.py"), "--mode", "self-play", "--rows", "6", "--cols", "6", "--simulations", "20",
+            "--episodes", "10", "--workers", "1", "--model-dir", str(mdir), "--blocks", "2", "--seed", "3"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = {}
+    for world in (1, 2):
+        ddir = tmp_path / f"data{world}"
+        cmd = ([sys.executable] if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", "29655"]) + base + ["--data-dir", str(ddir)] + (["--dist-backend", "gloo"] if world > 1 else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                        # rank 0 alone reports
+        z = np.load(json.loads(lines[0])["data_file"])
+        order = np.lexsort((z["ply"], z["game_id"]))
+        out[world] = {k: z[k][order] for k in z.files}
+    assert sorted(set(out[1]["game_id"].tolist())) == list(range(10))
+    for k in out[1]:
+        assert np.array_equal(out[1][k], out[2][k]), k
+
+
 def test_bench_json_contract(tmp_path):
     """bench.py prints ONE JSON line with the driver's contract keys, the roofline and cpu_baseline objects."""
     import json

@@ -49,6 +49,9 @@ def parse_args(argv=None):
                         "identical games); off: once per leaf, like the reference")
     p.add_argument("--reference-format", action="store_true",
                    help="self-play: also store the reference's pickled board objects so its own training pipeline reads the file")
+    p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                   help="collectives of a multi-rank launch: nccl = RCCL over xGMI (one rank per GPU); gloo = over the host, "
+                        "which also allows several ranks to share one GPU (rehearsals on a 1-GPU box)")
     p.add_argument("--arena-games", type=int, default=40)
     p.add_argument("--channels", type=int, default=128)
     p.add_argument("--blocks", type=int, default=10)
@@ -63,10 +66,15 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("train_alphazero.py: no ROCm device -- the self-play engine has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     import yinyang_game_alphazero_amd as pkg
     game = pkg.YinYangGame(args.rows, args.cols)
     for d in (args.model_dir, args.data_dir):

@@ -366,6 +366,8 @@ def gather_examples(ex, group=None, capacity=None):
         return ex
     world = dist.get_world_size(group)
     keys = sorted(ex)
+    if dist.get_backend(group) == "gloo" and ex[keys[0]].is_cuda:      # gloo gathers host buffers: stage the examples there
+        ex = {k: v.cpu() for k, v in ex.items()}
     dev = ex[keys[0]].device
     n = int(ex[keys[0]].shape[0])
     widths = [int(np.prod(ex[k].shape[1:], dtype=np.int64)) * ex[k].element_size() for k in keys]      # bytes per row and key
