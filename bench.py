@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--reuse-evaluations", type=int, default=0,
                     help="1 = the main leg runs with the engine's evaluation reuse (YY_FLAG_REUSE_PASS_VALUE | "
                          "YY_FLAG_REUSE_TRANSPOSITIONS | YY_FLAG_KEEP_EVALUATIONS); default 0: the evaluator is given every row the reference evaluates")
-    ap.add_argument("--reuse-steps", type=int, default=6, help="steps of the extra leg with evaluation reuse on (0 = skip)")
+    ap.add_argument("--reuse-steps", type=int, default=10, help="steps of the extra leg with evaluation reuse on (0 = skip)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
