@@ -49,7 +49,7 @@ extern "C" {
                               same value each time; with this flag the value of the first evaluation is kept in the
                               node record and a revisit takes it from there: no planes written, needs_eval = 0,
                               counters[6] += 1.  Visit counts, value sums and pi are unchanged (tests/test_gpu_mcts.py
-                              ::test_pass_value_reuse_*); counters[0] (evaluator rows) gets smaller.  Default off:
+                              ::test_evaluation_reuse_*); counters[0] (evaluator rows) gets smaller.  Default off:
                               the evaluator call sequence is then the reference's, row for row. */
 
 #define YY_FLAG_REUSE_TRANSPOSITIONS 8u /* evaluation cache, one search at a time.  The reference evaluates every leaf
