@@ -109,6 +109,36 @@ def test_alphazero_one_iteration(tmp_path):
     assert r["alphazero_wins"] + r["random_wins"] + r["draws"] == 6
 
 
+def test_alphazero_iteration_at_config5_size(tmp_path):
+    """BASELINE config 5 at its real size for ONE iteration with few episodes: 8x8 board, 800 simulations per move, the 128x10
+    network, the default (float32-accurate) evaluator with the engine's evaluation reuse, 10 000-example sampling cut to what the
+    games produce: GPU self-play -> training -> arena (800 simulations) -> promotion rule.  Checks what a run must hold: every
+    game contributes its positions with pi summing to 1 and z in {-1, 1, +-1e-4}, the loss falls, the arena accounts for every
+    game, the promotion follows the 0.6 rule, the checkpoints load into the reference's layout."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    game = pkg.YinYangGame(8, 8)
+    torch.manual_seed(0)
+    az = pkg.AlphaZero(game, model_dir=str(tmp_path / "models"), data_dir=str(tmp_path / "data"), num_iterations=1,
+                       num_episodes=32, num_simulations=800, num_epochs=2, arena_games=4, concurrent_games=32)
+    hist = az.run()
+    h = hist[0]
+    z = np.load(h["data_file"])
+    n = z["states"].shape[0]
+    assert len(np.unique(z["game_id"])) == 32 and 32 * 30 <= n <= 32 * 64
+    assert np.allclose(z["policies"].sum(1), 1.0, atol=1e-6) and set(np.unique(np.round(z["values"], 4))) <= {-1.0, 1.0, 0.0001, -0.0001}
+    assert (np.abs(z["states"]) <= 1).all() and (np.count_nonzero(z["states"].reshape(n, -1), axis=1) <= z["ply"]).all()   # a ply places at most one stone
+    assert len(h["losses"]) == 2 and h["losses"][1] < h["losses"][0] and np.isfinite(h["losses"]).all()
+    a = h["arena"]
+    assert a["a_wins"] + a["b_wins"] + a["draws"] == a["games"] == 4
+    assert h["promoted"] == (h["win_ratio"] >= 0.6)
+    for name in ("current_model.pth.tar", "best_model.pth.tar", "checkpoint_1.pth.tar"):
+        ck = torch.load(str(tmp_path / "models" / name), map_location="cpu", weights_only=True)
+        assert set(ck) == {"state_dict", "board_size", "action_size"} and tuple(ck["board_size"]) == (8, 8)
+    print("config-5-size iteration: self-play %.1f s (%d examples), train %.1f s (loss %.3f -> %.3f), arena %.1f s, win ratio %.2f" % (
+        h["self_play_s"], n, h["train_s"], h["losses"][0], h["losses"][1], h["arena_s"], h["win_ratio"]))
+
+
 def test_alphazero_player_api():
     import torch
     import yinyang_game_alphazero_amd as pkg
