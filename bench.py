@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--reuse-evaluations", type=int, default=0,
                     help="1 = the main leg runs with the engine's evaluation reuse (YY_FLAG_REUSE_PASS_VALUE | "
                          "YY_FLAG_REUSE_TRANSPOSITIONS | YY_FLAG_KEEP_EVALUATIONS); default 0: the evaluator is given every row the reference evaluates")
+    ap.add_argument("--book-stones", type=int, default=8,
+                    help="legs with evaluation reuse also get a shared opening book: every position reachable with at most this "
+                         "many stones, evaluated once before the timed region (0 = none; boards of at most 64 cells)")
     ap.add_argument("--reuse-steps", type=int, default=10, help="steps of the extra leg with evaluation reuse on (0 = skip)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
@@ -377,7 +380,15 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
     game = pkg.YinYangGame(args.rows, args.cols)
     net = pkg.YinYangNeuralNetwork(game, args.channels, args.blocks).to(dev).eval()
     evaluator = pkg.BatchedEvaluator(net, nn)
-    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games,
+    use_reuse = bool(args.reuse_evaluations if reuse is None else reuse)
+    book, book_s = None, 0.0
+    if use_reuse and args.book_stones > 0 and args.rows * args.cols <= 64 and getattr(evaluator, "row_independent", False):
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        book = pkg.engine.OpeningBook(args.rows, args.cols, evaluator, args.book_stones, device=dev)
+        torch.cuda.synchronize()
+        book_s = time.perf_counter() - tb
+    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games, opening_book=book,
                          board_semantics=args.semantics, reference_quirks=args.quirks,
                          use_graph=not args.no_graph, seed=1000, device=dev,
                          first_game_index=rank, game_index_stride=world,
@@ -388,6 +399,9 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
     leg = timed_region(eng, steps, warmup, rank, world, dist, cdev, args.sims,
                        capacity=example_capacity(games * world, world, eng.T))
     leg["nn"], leg["reuse"] = nn, eng.reuse_pass_value or eng.reuse_transpositions
+    if book is not None:
+        leg["book"] = dict(max_stones=book.max_stones, positions=book.n, stored=book.stored, bytes=book.bytes, build_s=book_s,
+                           note="evaluated once with the same evaluator before the timed region; shared by all games")
     if with_roofline and rank == 0:
         leg["roofline"] = make_roofline(args, eng, games)
     eng.close()
@@ -529,6 +543,7 @@ def main():
                                  "position this search or an earlier search of the same game has evaluated takes the cached policy row "
                                  "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
             s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated
+            s["opening_book"] = leg.get("book")
             # tree nodes expanded (Node.expand calls of the reference, mcts.py:397): by an evaluator row or from the cache
             s["node_expansions_per_s"] = (leg["evals"] + leg["served"]) / leg["dt"]
             extra["with_evaluation_reuse"] = s

@@ -192,6 +192,19 @@ int yy_mcts_get_boards(yy_mcts *ctx, int8_t *boards, yy_stream_t stream);
  * or the last yy_mcts_reset_counters.  Returns YY_E_ARENA if any game overflowed. */
 int yy_mcts_status(yy_mcts *ctx, int32_t *n_overflow, uint64_t *counters);
 int yy_mcts_reset_counters(yy_mcts *ctx, yy_stream_t stream);
+/* Shared book of pre-evaluated positions.  Every self-play game starts from the empty board, so the searches of the first plies
+ * of ALL games walk the same few hundred thousand positions (8x8: 770 232 positions with <= 8 stones are reachable).  The
+ * caller enumerates them, evaluates them once in large batches with the SAME evaluator the searches use, and hands the table
+ * to the contexts: a leaf with at most `max_stones` stones is looked up there first (same hash / probe / full key compare as
+ * the per-game cache) and, on a hit, needs no evaluator row (counters[7]).  Read-only during play, so no atomics on the
+ * lookup side; arrays stay owned by the caller and must outlive the context (or be unset with meta = NULL).
+ *   yy_book_insert: keys u64 [n, 2*NW] (black words, white words), distinct -> slot_of i32 [n] (-1 = no free slot within
+ *   the probe window); fills meta u32 [cap] (zeroed by the caller, cap a power of two) and table_keys u64 [cap, 2*NW].
+ *   The caller then scatters its value f32 [cap] and policy f32 [cap, A] rows by slot_of. */
+int yy_book_insert(const uint64_t *keys, int n, int R, int C, uint32_t *meta, uint64_t *table_keys, int64_t cap,
+                   int32_t *slot_of, yy_stream_t stream);
+int yy_mcts_set_book(yy_mcts *ctx, const uint32_t *meta, const uint64_t *keys, const float *value, const float *policy,
+                     int64_t cap, int max_stones);
 /* Forget every cached evaluation (YY_FLAG_REUSE_TRANSPOSITIONS / YY_FLAG_KEEP_EVALUATIONS): to be called when the evaluator
  * (the network) changes between two searches of one context.  Async on `stream`. */
 int yy_mcts_cache_clear(yy_mcts *ctx, yy_stream_t stream);

@@ -391,6 +391,76 @@ def test_evaluation_cache_replacement_keeps_results(pkg):
     assert min(hits[1:]) > 0, hits
 
 
+def test_opening_book_enumerates_the_reachable_positions(pkg):
+    """OpeningBook's breadth-first enumeration against the oracle's rules: the number of distinct positions alternating legal
+    play reaches with 1..6 stones on 8x8 (64, 4 032, 6 944, 11 848, 30 056, 75 432: same-colour stones must stay connected, so
+    the counts are far below the binomials), every one stored, and the stored evaluation of a sample is the evaluator's."""
+    import torch
+    from hash_eval import hash_eval_torch
+    E = pkg.engine
+    ev = lambda p: hash_eval_torch(p, 6, 4)
+    book = E.OpeningBook(8, 8, ev, 6)
+    assert book.n == 64 + 4032 + 6944 + 11848 + 30056 + 75432 and book.stored >= 0.9995 * book.n
+    # level by level with the oracle's legal masks (CPU restatement), the first three stone counts
+    b = np.zeros((1, 8, 8), np.int8)
+    player, want = 1, []
+    for _ in range(3):
+        m = O.valid_mask(b, np.full(len(b), player, np.int8))
+        bi, a = np.nonzero(m)
+        c = b[bi].reshape(len(bi), -1).copy()
+        c[np.arange(len(bi)), a] = player
+        b = np.unique(c, axis=0).reshape(-1, 8, 8)
+        want.append(len(b))
+        player = -player
+    assert want == [64, 4032, 6944]
+    # stored rows = the evaluator on that position
+    used = torch.nonzero(book.meta).reshape(-1)[:: max(1, book.n // 500)]
+    black, white = book.table_keys[used, 0].contiguous()[None], book.table_keys[used, 1].contiguous()[None]
+    boards = E.unpack_boards(black, white, 8, 8)
+    p, v = ev(E.encode_planes(boards))
+    assert torch.equal(p, book.policy[used]) and torch.equal(v, book.value[used])
+
+
+@pytest.mark.parametrize("shape,stones,G", [((8, 8), 5, 512), ((6, 6), 6, 256)], ids=["8x8", "6x6"])
+def test_opening_book_returns_the_same_search(pkg, shape, stones, G):
+    """Searches from opening positions (0..9 plies) with the shared book of pre-evaluated positions (yy_mcts_set_book), alone
+    and on top of the per-game evaluation cache: the same visit counts, value sums and pi as the plain search and the oracle;
+    the rows the evaluator is spared are counted (counters[7])."""
+    import torch
+    from hash_eval import hash_eval_torch
+    E = pkg.engine
+    R, C = shape
+    sims = 150
+    ev = lambda p: hash_eval_torch(p, 6, 4)
+    book = E.OpeningBook(R, C, ev, stones)
+    boards, players = _late_positions(E, G, R, C, 10, 21)
+    res = {}
+    for tag, kw, use_book in (("plain", {}, False), ("book", {}, True),
+                              ("book+cache", dict(reuse_pass_value=True, reuse_transpositions=True, keep_evaluations=True), True)):
+        m = E.BatchedMCTS(G, R, C, sims, **kw)
+        if use_book:
+            m.set_book(book)
+        c = m.search(boards, players, ev, sims)
+        res[tag] = (c.cpu().numpy(), m.root_stats()[1].cpu().numpy(), m.root_policy().cpu().numpy(), m.status())
+        if use_book and tag == "book":          # unset: the plain search again on the same context
+            m.set_book(None)
+            m.reset_counters()
+            c2 = m.search(boards, players, ev, sims)
+            assert torch.equal(c, c2) and m.status()["transposition_hits"] == 0
+        m.close()
+    k0 = res["plain"][3]
+    for tag in ("book", "book+cache"):
+        for i in range(3):
+            assert np.array_equal(res["plain"][i], res[tag][i]), (tag, i)
+        k1 = res[tag][3]
+        assert k1["evals"] + k1["reused_values"] + k1["transposition_hits"] == k0["evals"] and k1["nodes"] == k0["nodes"]
+    assert res["book"][3]["transposition_hits"] > 0.05 * k0["evals"]       # the shallow leaves live in the book
+    assert res["book+cache"][3]["evals"] < res["book"][3]["evals"]
+    bh, ph = boards.cpu().numpy(), players.cpu().numpy()
+    for g in np.random.default_rng(5).choice(G, 16, replace=False):
+        assert np.array_equal(res["book+cache"][0][g], O.search_hash(bh[g], int(ph[g]), sims, 1, 6, 4).counts), g
+
+
 def test_evaluation_cache_with_aliased_boards_and_clear(pkg):
     """The cache is keyed by the position, so it also serves the literal aliased-board search (the shared board a leaf is
     evaluated on is looked up as it is at that moment); yy_mcts_cache_clear forgets everything (a new network)."""

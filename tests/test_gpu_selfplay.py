@@ -401,6 +401,29 @@ def test_evaluation_reuse_plays_the_same_games(pkg, shape, G, games, sims):
         on["transposition_hits"]))
 
 
+def test_opening_book_plays_the_same_games(pkg):
+    """Whole 6x6 games with the live split-f16 evaluator and an opening book of every position with <= 6 stones (built with the
+    same evaluator, in batches): the examples are bit-identical to the engine without a book, and the evaluator is spared the
+    shallow rows of every game."""
+    import torch
+    game = pkg.YinYangGame(6, 6)
+    torch.manual_seed(0)
+    ev = pkg.BatchedEvaluator(pkg.YinYangNeuralNetwork(game, 128, 2).cuda().eval())
+    runs, ctrs = [], []
+    for book in (6, None):
+        eng = pkg.SelfPlayEngine(game, ev, num_simulations=48, concurrent_games=96, seed=9, opening_book=book)
+        assert (eng.book is not None) == (book is not None)
+        ex = eng.run(160)
+        order = torch.argsort(ex["game_id"] * 1000 + ex["ply"])
+        runs.append({k: v[order].cpu() for k, v in ex.items()})
+        ctrs.append(eng.ctx.status())
+        eng.close()
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    assert ctrs[0]["evals"] < ctrs[1]["evals"]
+    print("opening book <= 6 stones on 6x6: evaluator rows %d -> %d" % (ctrs[1]["evals"], ctrs[0]["evals"]))
+
+
 # ---- per-game counter-based random streams (csrc/yy_selfplay.hip)
 def test_sample_actions_kernel_equals_host_restatement(pkg):
     """yy_selfplay_sample_actions against tests/philox_ref.py (Philox4x32-10 pinned by Random123's known answers): same

@@ -79,6 +79,8 @@ _SIGS = {
     "yy_mcts_status": [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)],
     "yy_mcts_reset_counters": [_vp, _vp],
     "yy_mcts_cache_clear": [_vp, _vp],
+    "yy_book_insert": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp, _vp],
+    "yy_mcts_set_book": [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int],
     "yy_nn_bias_act_bf16": [_vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, _vp],
     "yy_nn_tower_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

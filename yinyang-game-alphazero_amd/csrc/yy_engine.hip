@@ -447,6 +447,22 @@ enum : uint8_t { K_NONE = 0, K_TERMINAL = 1, K_EXPAND = 2, K_REEXPAND = 3, K_ROO
 #define NF_HASVALUE 2u   // childless node whose evaluator value (record .w) may be reused (YY_FLAG_REUSE_PASS_VALUE)
 #define TT_PROBES 8
 
+// slot hash of a position: murmur3's 64-bit finalizer after every word -- positions of one search differ in a few bits, and a
+// single multiply leaves the low bits (the slot index) clustered (measured: probe runs of 8 at 5 % load)
+template <int NW> __device__ __forceinline__ uint64_t bb_hash(const uint64_t *black, const uint64_t *white) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int i = 0; i < 2 * NW; i++) {
+        h ^= (i < NW) ? black[i] : white[i - NW];
+        h ^= h >> 33;
+        h *= 0xFF51AFD7ED558CCDull;
+        h ^= h >> 33;
+        h *= 0xC4CEB9FE1A85EC53ull;
+        h ^= h >> 33;
+    }
+    return h;
+}
+
 struct GameState {
     int32_t n_nodes, n_edges;
     int32_t root_N;
@@ -483,6 +499,12 @@ struct yy_mcts {
     float *ec_val;          // [G, ec_cap]  the evaluator's value
     float *ec_pol;          // [G, ec_cap, A]  the evaluator's policy row
     int64_t ec_cap;
+    // shared book of pre-evaluated positions (yy_mcts_set_book; arrays owned by the caller, read-only here)
+    const uint32_t *bk_meta;
+    const uint64_t *bk_key;
+    const float *bk_val, *bk_pol;
+    int64_t bk_cap;
+    int bk_stones;
     GameState *state;
     float *sqrt_tab;
     uint64_t *scratch;      // [8] counters + overflow count
@@ -505,6 +527,11 @@ struct MctsDev {  // by-value kernel argument
     float *ec_val, *ec_pol;
     int32_t ec_cap;
     uint32_t ec_keep;
+    const uint32_t *bk_meta;
+    const uint64_t *bk_key;
+    const float *bk_val, *bk_pol;
+    uint32_t bk_mask;
+    int32_t bk_stones;
     GameState *state;
     const float *sqrt_tab;
     int32_t sqrt_n;
@@ -532,6 +559,12 @@ static MctsDev make_dev(const yy_mcts *c) {
     d.ec_pol = c->ec_pol;
     d.ec_cap = (int32_t)c->ec_cap;
     d.ec_keep = (c->cfg.flags & YY_FLAG_KEEP_EVALUATIONS) ? 1u : 0u;
+    d.bk_meta = c->bk_meta;
+    d.bk_key = c->bk_key;
+    d.bk_val = c->bk_val;
+    d.bk_pol = c->bk_pol;
+    d.bk_mask = (uint32_t)(c->bk_cap - 1);
+    d.bk_stones = c->bk_stones;
     d.state = c->state;
     d.sqrt_tab = c->sqrt_tab;
     d.sqrt_n = c->cfg.max_sims + 2;
@@ -754,19 +787,27 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
         // with YY_FLAG_KEEP_EVALUATIONS, an earlier search of the same game -- needs no evaluator row: the cached policy row
         // and value ARE this leaf's evaluation.  Keys are compared in full; the hash only picks the probe sequence.
         int src = -1, slot = -1;
-        if (d.ec_meta) {
-            // murmur3's 64-bit finalizer after every word: positions of one search differ in a few bits, and a single
-            // multiply leaves the low bits (the slot index) clustered -- measured: probe runs of 8 at 5 % load
-            uint64_t h = 0x9E3779B97F4A7C15ull;
+        uint64_t h = 0;
+        if (d.ec_meta || d.bk_meta) h = bb_hash<NW>(black.w, white.w);
+        if (d.bk_meta) {
+            // the shared book (yy_mcts_set_book): positions of the first plies evaluated once for ALL games before play; read-only
+            int stones = 0;
 #pragma unroll
-            for (int i = 0; i < 2 * NW; i++) {
-                h ^= (i < NW) ? black.w[i] : white.w[i - NW];
-                h ^= h >> 33;
-                h *= 0xFF51AFD7ED558CCDull;
-                h ^= h >> 33;
-                h *= 0xC4CEB9FE1A85EC53ull;
-                h ^= h >> 33;
+            for (int i = 0; i < NW; i++) stones += yy_popc64(black.w[i]) + yy_popc64(white.w[i]);
+            if (stones <= d.bk_stones) {
+                uint32_t at = (uint32_t)h & d.bk_mask;
+                for (int pr = 0; pr < TT_PROBES; pr++, at = (at + 1u) & d.bk_mask) {
+                    if (rfl((int)d.bk_meta[at]) == 0) break;
+                    const BB<NW> ob = bb_uniform_load<NW>(d.bk_key + (size_t)at * 2 * NW),
+                                 ow = bb_uniform_load<NW>(d.bk_key + (size_t)at * 2 * NW + NW);
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < NW; i++) same = same && ob.w[i] == black.w[i] && ow.w[i] == white.w[i];
+                    if (same) { src = -2 - (int)at; break; }
+                }
             }
+        }
+        if (d.ec_meta && src == -1) {
             const uint32_t *meta = d.ec_meta + (size_t)g * d.ec_cap;
             const uint64_t *keys = d.ec_key + (size_t)g * d.ec_cap * 2 * NW;
             const uint32_t mask_c = (uint32_t)d.ec_cap - 1u;
@@ -791,7 +832,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             }
             if (slot < 0) slot = (int)at0;                                     // every probed entry is live: replace the first
         }
-        if (src < 0) write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
+        if (src == -1) write_planes<NW>(planes + (size_t)g * 5 * d.geo.A, d.geo, black, white);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NW; i++) {
@@ -805,7 +846,7 @@ __device__ __forceinline__ void do_select(const MctsDev &d, const int g, float *
             st->leaf_src = src;
             st->leaf_ec_slot = slot;
         }
-        need = src < 0;
+        need = src == -1;
         if (!need && lane == 0) st->ctr[7] += 1;
     }
     if (lane == 0) {
@@ -842,10 +883,12 @@ __device__ __forceinline__ void do_expand_backup(const MctsDev &d, const int g, 
     } else if (kind == K_REUSE) {
         v = rflf(__uint_as_float(nodes[node].w));                                   // the np.float32 the evaluator returned for this node
     } else {
-        const int src = (d.ec_meta && kind != K_ROOTINIT) ? rfl(st->leaf_src) : -1;
-        const bool copy = src >= 0;                                                 // evaluation taken from cache slot `src`
-        const float *cpol = copy ? d.ec_pol + ((size_t)g * d.ec_cap + src) * d.geo.A : nullptr;
-        v = (kind == K_ROOTINIT) ? 0.0f : copy ? rflf(d.ec_val[(size_t)g * d.ec_cap + src]) : rflf(value[g]);
+        const int src = ((d.ec_meta || d.bk_meta) && kind != K_ROOTINIT) ? rfl(st->leaf_src) : -1;
+        const bool copy = src != -1;             // evaluation taken from the game's cache (slot src >= 0) or the book (slot -2 - src)
+        const float *cpol = src >= 0 ? d.ec_pol + ((size_t)g * d.ec_cap + src) * d.geo.A
+                                     : copy ? d.bk_pol + (size_t)(-2 - src) * d.geo.A : nullptr;
+        v = (kind == K_ROOTINIT) ? 0.0f
+            : src >= 0 ? rflf(d.ec_val[(size_t)g * d.ec_cap + src]) : copy ? rflf(d.bk_val[-2 - src]) : rflf(value[g]);
         if (v != v) {   // a NaN from the evaluator must not enter the statistics: the game stops searching, the error is sticky
             if (lane == 0) { st->err = st->err_ever = 1; st->leaf_kind = K_NONE; }
             return;
@@ -1263,6 +1306,44 @@ extern "C" int yy_mcts_status(yy_mcts *c, int32_t *n_overflow, uint64_t *counter
     }
     if (n_overflow) *n_overflow = (int32_t)h[8];
     if (h[8]) return set_err(YY_E_ARENA, "tree arena overflow or non-finite evaluator output in at least one game since the last status call%s%s");
+    return YY_OK;
+}
+
+// ---- shared book of pre-evaluated positions
+template <int NW> __global__ void k_book_insert(const uint64_t *__restrict__ keys, int n, uint32_t *meta, uint64_t *tkeys,
+                                                uint32_t mask, int32_t *slot_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *k = keys + (size_t)i * 2 * NW;
+    uint32_t at = (uint32_t)bb_hash<NW>(k, k + NW) & mask;
+    int got = -1;
+    for (int pr = 0; pr < TT_PROBES; pr++, at = (at + 1u) & mask)
+        if (atomicCAS(&meta[at], 0u, 1u) == 0u) { got = (int)at; break; }      // keys are distinct: a taken slot is another position
+    if (got >= 0)
+        for (int j = 0; j < 2 * NW; j++) tkeys[(size_t)got * 2 * NW + j] = k[j];
+    slot_of[i] = got;      // -1: no free slot within the probe window (the position stays out of the book)
+}
+
+extern "C" int yy_book_insert(const uint64_t *keys, int n, int R, int C, uint32_t *meta, uint64_t *table_keys, int64_t cap,
+                              int32_t *slot_of, yy_stream_t s) {
+    if (n == 0) return YY_OK;
+    if (!keys || !meta || !table_keys || !slot_of || n < 0 || cap < 64 || (cap & (cap - 1)) || cap > (1ll << 31))
+        return set_err(YY_E_INVALID, "yy_book_insert: bad argument (cap must be a power of two)%s%s");
+    if (int e = check_geo(1, R, C)) return e;
+    const int nw = (R * C + 63) / 64;
+    DISPATCH_NW(nw, k_book_insert<NW><<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s>>>(keys, n, meta, table_keys,
+                                                                                               (uint32_t)(cap - 1), slot_of));
+    HIP_TRY(hipGetLastError());
+    return YY_OK;
+}
+
+extern "C" int yy_mcts_set_book(yy_mcts *c, const uint32_t *meta, const uint64_t *keys, const float *val, const float *pol,
+                                int64_t cap, int max_stones) {
+    if (!c) return set_err(YY_E_INVALID, "null pointer%s%s");
+    if (!meta) { c->bk_meta = nullptr; c->bk_key = nullptr; c->bk_val = c->bk_pol = nullptr; c->bk_cap = 0; c->bk_stones = 0; return YY_OK; }
+    if (!keys || !val || !pol || cap < 64 || (cap & (cap - 1)) || cap > (1ll << 31) || max_stones < 1)
+        return set_err(YY_E_INVALID, "yy_mcts_set_book: bad argument (cap must be a power of two)%s%s");
+    c->bk_meta = meta; c->bk_key = keys; c->bk_val = val; c->bk_pol = pol; c->bk_cap = cap; c->bk_stones = max_stones;
     return YY_OK;
 }
 

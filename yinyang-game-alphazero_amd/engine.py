@@ -338,6 +338,63 @@ def sample_actions(seed, game_id, ply, searching, pi, mask, temperature_threshol
     return out
 
 
+# ------------------------------------------------------------------ shared book of pre-evaluated opening positions
+class OpeningBook:
+    """Every position with at most `max_stones` stones that alternating legal play reaches from the empty board (8x8: 770 232
+    for max_stones = 8), evaluated ONCE with `evaluator` in batches of `batch` rows and stored as an open-addressing table in
+    HBM [position -> policy row f32[A], value].  BatchedMCTS.set_book(book) makes every search look its shallow leaves up
+    there before asking the evaluator (include/yy_engine.h: yy_mcts_set_book): all games start from the empty board, so the
+    first plies of thousands of games walk the same positions.  The evaluator must be the one the searches use, and a
+    deterministic function of the row (BatchedEvaluator.row_independent); the results of a search are then unchanged."""
+
+    def __init__(self, R, C, evaluator, max_stones, rowcol=False, batch=4096, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.R, self.C, self.A, self.max_stones = int(R), int(C), int(R) * int(C), int(max_stones)
+        nw = (self.A + 63) // 64
+        boards = torch.zeros((1, R, C), dtype=torch.int8, device=dev)
+        player, keys, states = 1, [], []
+        for _ in range(self.max_stones):                       # breadth-first over stone counts; a side without a move ends a line
+            players = torch.full((boards.shape[0],), player, dtype=torch.int8, device=dev)
+            bi, a = valid_mask(boards, players, rowcol).nonzero(as_tuple=True)
+            if bi.numel() == 0:
+                break
+            child = boards.reshape(-1, self.A)[bi]
+            child[torch.arange(bi.numel(), device=dev), a] = player
+            black, white = pack_boards(child.view(-1, R, C))
+            key = torch.cat([black.t(), white.t()], dim=1).contiguous()                 # [m, 2*NW]
+            uniq, inv = torch.unique(key, dim=0, return_inverse=True)
+            first = torch.zeros(uniq.shape[0], dtype=torch.int64, device=dev)
+            first[inv] = torch.arange(key.shape[0], device=dev)                         # any representative of each position
+            boards = child[first].view(-1, R, C).contiguous()
+            keys.append(uniq)
+            states.append(boards)
+            player = -player
+        self.keys = torch.cat(keys).contiguous()
+        boards = torch.cat(states)
+        self.n = int(self.keys.shape[0])
+        pol = torch.empty((self.n, self.A), dtype=torch.float32, device=dev)
+        val = torch.empty(self.n, dtype=torch.float32, device=dev)
+        for lo in range(0, self.n, batch):                                              # the evaluations: n / batch launches
+            p, v = evaluator(encode_planes(boards[lo:lo + batch].contiguous()))
+            pol[lo:lo + batch], val[lo:lo + batch] = p, v
+        self.cap = 64
+        while self.cap < 6 * self.n:                   # load <= 1/6: next to no probe run reaches the 8-step window
+            self.cap *= 2
+        self.meta = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.table_keys = torch.zeros((self.cap, 2 * nw), dtype=torch.int64, device=dev)
+        slot = torch.empty(self.n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().yy_book_insert(_p(self.keys), self.n, R, C, _p(self.meta), _p(self.table_keys), self.cap, _p(slot), _stream()))
+        ok = slot >= 0
+        self.stored = int(ok.sum())
+        idx = slot[ok].long()
+        self.value = torch.zeros(self.cap, dtype=torch.float32, device=dev)
+        self.policy = torch.zeros((self.cap, self.A), dtype=torch.float32, device=dev)
+        self.value[idx] = val[ok]
+        self.policy[idx] = pol[ok]
+        self.bytes = sum(t.numel() * t.element_size() for t in (self.meta, self.table_keys, self.value, self.policy))
+
+
 # ------------------------------------------------------------------ batched MCTS context
 class BatchedMCTS:
     """G games searched in lockstep on one GPU; replaces Node + MCTS.search/_simulate
@@ -459,6 +516,19 @@ class BatchedMCTS:
         with torch.cuda.device(self.device):
             check(lib().yy_mcts_status(self._h, ct.byref(n), ctr))
         return dict(zip(self.COUNTERS, [int(x) for x in ctr[:8]]))
+
+    def set_book(self, book):
+        """Shallow leaves are looked up in `book` (OpeningBook, or None to unset) before the evaluator is asked; the context
+        keeps a reference so that the table outlives its use."""
+        if book is not None and (book.R, book.C) != (self.R, self.C):
+            raise _lib.YYError(-1, "the book was built for another board size")
+        with torch.cuda.device(self.device):
+            if book is None:
+                check(lib().yy_mcts_set_book(self._h, None, None, None, None, 0, 0))
+            else:
+                check(lib().yy_mcts_set_book(self._h, _p(book.meta), _p(book.table_keys), _p(book.value), _p(book.policy),
+                                             book.cap, book.max_stones))
+        self.book = book
 
     def clear_evaluation_cache(self):
         with torch.cuda.device(self.device):

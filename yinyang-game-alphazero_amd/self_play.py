@@ -121,7 +121,8 @@ class SelfPlayEngine:
                  dirichlet_alpha=0.3, dirichlet_epsilon=0.25, temperature_threshold=10,
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
                  device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None,
-                 reuse_pass_value=None, reuse_transpositions=None, keep_evaluations=None):
+                 reuse_pass_value=None, reuse_transpositions=None, keep_evaluations=None,
+                 opening_book=None):
         """reuse_pass_value / reuse_transpositions / keep_evaluations: None = on when the boards are copied and the evaluator
         declares `row_independent` (the split-f16 evaluator does).  The reference asks the network for every leaf: a node
         without legal moves again on every visit (ai/mcts.py:93-95, 371-397), a position another move order of the same search
@@ -129,7 +130,10 @@ class SelfPlayEngine:
         With these options the search takes them from the tree / from a per-game evaluation cache in HBM instead
         (YY_FLAG_REUSE_PASS_VALUE, YY_FLAG_REUSE_TRANSPOSITIONS, YY_FLAG_KEEP_EVALUATIONS in include/yy_engine.h).  The games
         played are the same, move for move; the evaluator sees a fraction of the rows.  The engine owns ONE evaluator for its
-        lifetime, which is what keep_evaluations needs."""
+        lifetime, which is what keep_evaluations needs.
+        opening_book: an engine.OpeningBook built with THIS evaluator, or a stone count N to build one here (every position
+        reachable with <= N stones is evaluated once, in large batches, before play; all games start from the empty board, so
+        the first plies of every game search the same positions), or None."""
         assert board_semantics in ("aliased", "copied")
         self.game = game
         self.R, self.C = game.getBoardSize()
@@ -154,6 +158,12 @@ class SelfPlayEngine:
         self.ctx = engine.BatchedMCTS(self.G, self.R, self.C, self.sims, cpuct=cpuct, aliased=self.aliased,
                                       rowcol=self.rowcol, device=self.device, reuse_pass_value=self.reuse_pass_value,
                                       reuse_transpositions=self.reuse_transpositions, keep_evaluations=self.keep_evaluations)
+        if isinstance(opening_book, int):
+            opening_book = (engine.OpeningBook(self.R, self.C, evaluator, opening_book, rowcol=self.rowcol, device=self.device)
+                            if opening_book > 0 else None)
+        self.book = opening_book
+        if opening_book is not None:
+            self.ctx.set_book(opening_book)
         self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
         self.seed = int(seed)                      # key of the per-game counter streams (csrc/yy_selfplay.hip)
         self.n_alive = 0                           # live games, tracked on the host (no device read needed)
@@ -525,10 +535,14 @@ class SelfPlayManager:
     def __init__(self, game, model_path, num_workers=1, num_simulations=800, games_per_worker=1,
                  temperature_threshold=10, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0,
                  mcts_parallel=1, concurrent_games=4096, board_semantics="copied", reference_quirks=False,
-                 nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10, evaluation_reuse=None):
+                 nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10, evaluation_reuse=None,
+                 opening_book_stones=None):
         """evaluation_reuse: None = the engine's default (on for copied boards with the float32-accurate evaluator: pass values +
         per-game evaluation cache, SelfPlayEngine); False = the network is asked for every leaf like the reference."""
         self.evaluation_reuse = evaluation_reuse
+        # None = 8 stones when it pays: evaluation reuse on, a board of at most 64 cells (770 k positions at 8x8: ~1.5 s to build)
+        # and at least 1024 games for this rank; 0 = no book
+        self.opening_book_stones = opening_book_stones
         self.game, self.model_path = game, model_path
         self.num_workers, self.games_per_worker = num_workers, games_per_worker
         self.num_simulations, self.temperature_threshold = num_simulations, temperature_threshold
@@ -549,7 +563,13 @@ class SelfPlayManager:
         if os.path.exists(self.model_path):
             net.load_model(self.model_path)       # every rank reads the same file: no broadcast needed
         net = net.to(dev).eval()
-        eng = SelfPlayEngine(self.game, BatchedEvaluator(net, self.nn_mode), num_simulations=self.num_simulations,
+        evaluator = BatchedEvaluator(net, self.nn_mode)
+        book = self.opening_book_stones
+        if book is None:
+            auto = (self.evaluation_reuse is not False and self.board_semantics == "copied" and mine >= 1024
+                    and self.game.getActionSize() <= 64 and getattr(evaluator, "row_independent", False))
+            book = 8 if auto else 0
+        eng = SelfPlayEngine(self.game, evaluator, num_simulations=self.num_simulations, opening_book=int(book),
                              concurrent_games=max(1, min(self.concurrent_games, mine)), cpuct=self.cpuct,
                              dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                              temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
