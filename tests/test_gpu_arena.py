@@ -268,6 +268,7 @@ def test_bench_json_contract(tmp_path):
     ru = d["with_evaluation_reuse"]
     assert ru["nn"] == "f16x3" and ru["value"] > 0 and ru["evaluator_rows_per_s"] > 0 and ru["eval_fraction"] <= tree["eval_fraction"] + 0.02
     assert ru["node_expansions_per_s"] >= ru["evaluator_rows_per_s"]
+    assert ru["opening_book"]["positions"] == ru["opening_book"]["stored"] == 769880 and ru["opening_book"]["build_s"] > 0
 
 
 @pytest.mark.parametrize("nproc,backend", [(2, "gloo"), (1, "nccl")], ids=["2 ranks on one GPU, gloo", "1 rank, RCCL"])
