@@ -18,6 +18,7 @@ ap.add_argument("--nn", default="auto", help="auto = float32-accurate (f16x3); b
 ap.add_argument("--rows", type=int, default=8)
 ap.add_argument("--single", action="store_true", help="only the plain run (no 2x refilled run)")
 ap.add_argument("--reuse", type=int, default=1, help="1 = the engine's evaluation reuse (its default); 0 = the evaluator gets every row the reference evaluates")
+ap.add_argument("--book", type=int, default=0, help="shared opening book: positions with at most this many stones (0 = none)")
 ap.add_argument("--out", default="gpurun_out/config2_full.json")
 a = ap.parse_args()
 torch.manual_seed(0)
@@ -27,8 +28,8 @@ ev = pkg.BatchedEvaluator(net, a.nn)
 res = []
 for total in ((a.games,) if a.single else (a.games, 2 * a.games)):
     kw = {} if a.reuse else dict(reuse_pass_value=False, reuse_transpositions=False, keep_evaluations=False)
-    eng = SelfPlayEngine(game, ev, num_simulations=a.sims, concurrent_games=a.slots, seed=1000, **kw)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize(); t0 = time.perf_counter()          # the book's build time is inside the wall time
+    eng = SelfPlayEngine(game, ev, num_simulations=a.sims, concurrent_games=a.slots, seed=1000, opening_book=a.book, **kw)
     last = [t0]
 
     def progress(e):
@@ -41,7 +42,7 @@ for total in ((a.games,) if a.single else (a.games, 2 * a.games)):
     n = int(ex["values"].shape[0])
     plies = torch.bincount(ex["game_id"] - ex["game_id"].min()).float()
     r = dict(board=f"{a.rows}x{a.rows}", games=total, slots=a.slots, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
-             evaluation_reuse=bool(a.reuse), evaluator_rows=int(c["evals"]), evaluator_rows_per_s=c["evals"] / dt,
+             evaluation_reuse=bool(a.reuse), opening_book_stones=a.book, book_positions=(eng.book.n if eng.book is not None else 0), evaluator_rows=int(c["evals"]), evaluator_rows_per_s=c["evals"] / dt,
              pass_values_reused=int(c["reused_values"]), cache_hits=int(c["transposition_hits"]),
              simulations_per_s=n * a.sims / dt, plies_mean=float(plies.mean()),
              plies_min=int(plies.min()), plies_max=int(plies.max()),

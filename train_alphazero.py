@@ -49,6 +49,9 @@ def parse_args(argv=None):
                         "identical games); off: once per leaf, like the reference")
     p.add_argument("--reference-format", action="store_true",
                    help="self-play: also store the reference's pickled board objects so its own training pipeline reads the file")
+    p.add_argument("--opening-book-stones", type=int, default=None,
+                   help="shared opening book: every position reachable with at most N stones is evaluated once before play "
+                        "(default: 8 when evaluation reuse is on, the board has at most 64 cells and the rank plays >= 1024 games; 0 = none)")
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="collectives of a multi-rank launch: nccl = RCCL over xGMI (one rank per GPU); gloo = over the host, "
                         "which also allows several ranks to share one GPU (rehearsals on a 1-GPU box)")
@@ -105,7 +108,8 @@ def main(argv=None):
                                        reference_quirks=args.reference_quirks, nn_mode=args.nn, seed=args.seed,
                                        num_channels=args.channels, num_res_blocks=args.blocks,
                                        reference_format=args.reference_format,
-                                       evaluation_reuse=None if args.evaluation_reuse == "auto" else False)
+                                       evaluation_reuse=None if args.evaluation_reuse == "auto" else False,
+                                       opening_book_stones=args.opening_book_stones)
     if rank == 0:
         st = pkg.generate_self_play_data.last_stats
         st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])
