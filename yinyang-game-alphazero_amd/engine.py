@@ -345,9 +345,10 @@ class OpeningBook:
     HBM [position -> policy row f32[A], value].  BatchedMCTS.set_book(book) makes every search look its shallow leaves up
     there before asking the evaluator (include/yy_engine.h: yy_mcts_set_book): all games start from the empty board, so the
     first plies of thousands of games walk the same positions.  The evaluator must be the one the searches use, and a
-    deterministic function of the row (BatchedEvaluator.row_independent); the results of a search are then unchanged."""
+    deterministic function of the row (BatchedEvaluator.row_independent); the results of a search are then unchanged.
+    max_positions bounds the table: enumeration stops before the stone count that would exceed it (max_stones is lowered)."""
 
-    def __init__(self, R, C, evaluator, max_stones, rowcol=False, batch=4096, device=None):
+    def __init__(self, R, C, evaluator, max_stones, rowcol=False, batch=4096, device=None, max_positions=8_000_000):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.R, self.C, self.A, self.max_stones = int(R), int(C), int(R) * int(C), int(max_stones)
         nw = (self.A + 63) // 64
@@ -365,10 +366,15 @@ class OpeningBook:
             uniq, inv = torch.unique(key, dim=0, return_inverse=True)
             first = torch.zeros(uniq.shape[0], dtype=torch.int64, device=dev)
             first[inv] = torch.arange(key.shape[0], device=dev)                         # any representative of each position
+            if sum(k.shape[0] for k in keys) + uniq.shape[0] > max_positions:           # keep whole stone counts only
+                self.max_stones = len(keys)
+                break
             boards = child[first].view(-1, R, C).contiguous()
             keys.append(uniq)
             states.append(boards)
             player = -player
+        if not keys:
+            raise _lib.YYError(-1, "OpeningBook: nothing to store (max_stones < 1 or max_positions too small)")
         self.keys = torch.cat(keys).contiguous()
         boards = torch.cat(states)
         self.n = int(self.keys.shape[0])
