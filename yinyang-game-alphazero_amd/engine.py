@@ -535,6 +535,7 @@ class BatchedMCTS:
                 check(lib().yy_mcts_set_book(self._h, _p(book.meta), _p(book.table_keys), _p(book.value), _p(book.policy),
                                              book.cap, book.max_stones))
         self.book = book
+        self.book_version = getattr(self, "book_version", 0) + 1      # captured steps hold the table's pointers: LockstepSearch re-captures
 
     def clear_evaluation_cache(self):
         with torch.cuda.device(self.device):

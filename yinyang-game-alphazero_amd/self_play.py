@@ -42,6 +42,7 @@ class LockstepSearch:
         self.graphs = {}       # evaluated rows -> captured step
         self.timer = None      # optional object with start()/stop() bracketing every tree-kernel launch (bench.py)
         self._policy = self._value = None
+        self._book_version = getattr(ctx, "book_version", 0)
 
     @property
     def graph(self):
@@ -86,6 +87,9 @@ class LockstepSearch:
         """rows: evaluate only leaf rows [0, rows) -- the caller guarantees every active game has an index below it
         (SelfPlayEngine packs the live games to the front when a batch drains).  One graph per distinct `rows`."""
         ctx = self.ctx
+        if getattr(ctx, "book_version", 0) != self._book_version:       # kernel arguments of a captured step are frozen: the book changed
+            self.graphs.clear()
+            self._book_version = getattr(ctx, "book_version", 0)
         rows = ctx.G if rows is None else min(int(rows), ctx.G)
         ctx.begin(boards, root_players, active)
         policy, _ = self._evaluate(rows)                       # mcts.py:295, value discarded
