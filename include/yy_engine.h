@@ -290,6 +290,16 @@ int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, const void 
                            int R, int C, int channels, int n_layers, int weight_exp, int head_exp,
                            int act_exp, yy_stream_t stream);
 
+/* 8x8 only: the same tower + head convolutions on the compacted rows (rows / n_rows as above, both required), with the kernel
+ * form chosen ON THE DEVICE from *n_rows: at most `split` live rows -> one board per workgroup with the LDS weight ring (twice
+ * as many CUs busy while the chip is not full), more -> two boards per workgroup with the register ring.  Both forms are
+ * launched, each gated on *n_rows; they write identical bits.  weights_lds as for yy_nn_tower_heads_f16x3, weights_regs /
+ * head_w_regs as for yy_nn_tower_f16x3_regs. */
+int yy_nn_tower_heads_f16x3_auto(const float *planes, const void *weights_lds, const void *weights_regs,
+                                 const void *head_w_regs, const float *bias, float *out_heads, const int32_t *rows,
+                                 const int32_t *n_rows, int G, int R, int C, int channels, int n_layers, int weight_exp,
+                                 int head_exp, int act_exp, int split, yy_stream_t stream);
+
 /* float32 head finish (neural_network.py:115, 120-121, 152): logits float32 [G,A] (policy_fc output, bias added), hidden
  * float32 [G,H] (value_fc1 output, bias added) of dense row i -> policy[g] = softmax(logits[i]),
  * value[g] = tanh(relu(hidden[i]) . w2 + b2), g = rows ? rows[i] : i, for i < (n_rows ? *n_rows : G). */

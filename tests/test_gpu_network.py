@@ -409,3 +409,34 @@ def test_split_f16_register_ring_kernel_equals_lds_ring_kernel(R):
     if R == 8:      # a small batch (one board per workgroup) gives the same bits for the same boards
         f_small = pkg.engine.tower_heads_forward_h3(planes[:100].contiguous(), ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)
         assert torch.equal(f_small, f_q[:100])
+
+
+def test_split_f16_form_chosen_on_the_device_writes_the_same_bits():
+    """engine.tower_heads_forward_h3_auto: both 8x8 kernel forms are launched, gated on the device-side live row count (<= 320
+    rows: one board per workgroup, more: two boards per workgroup with the register ring).  For row counts on both sides of the
+    split, at it, zero and the whole batch: the rows written equal the register-ring kernel's bit for bit, rows past the count
+    stay untouched, and the evaluator (which takes this path for 256 < G <= 2048) returns what the dense evaluation returns."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    E = pkg.engine
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
+    ev = pkg.BatchedEvaluator(net, "f16x3")
+    G = 1024
+    rng = np.random.default_rng(4)
+    planes = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
+    dense_p, dense_v = ev(planes)
+    for n_live in (0, 1, 7, 319, 320, 321, 600, 1024):
+        flags = torch.zeros(G, dtype=torch.uint8, device="cuda")
+        flags[torch.from_numpy(rng.choice(G, n_live, replace=False)).cuda()] = 1
+        rows, n = E.compact_rows(flags)
+        assert int(n) == n_live
+        want = torch.full((G, 2, 2048), -7.0, device="cuda")
+        got = want.clone()
+        E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n, want)
+        E.tower_heads_forward_h3_auto(planes, ev.h3_w, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n, 320, got)
+        assert torch.equal(want, got), n_live
+        assert n_live == G or bool((got[n_live:] == -7.0).all())
+        p, v = ev(planes, needs_eval=flags)
+        live = flags.bool()
+        assert torch.equal(p[live], dense_p[live]) and torch.equal(v[live], dense_v[live]), n_live

@@ -91,6 +91,8 @@ _SIGS = {
     "yy_nn_tower_heads_f16x3": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_head_finish_f32": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "yy_compact_rows": [_vp, C.c_int, _vp, _vp, _vp],
+    "yy_nn_tower_heads_f16x3_auto": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_f16x3_regs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, _vp],
     "yy_selfplay_root_noise": [C.c_uint64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp, _vp],

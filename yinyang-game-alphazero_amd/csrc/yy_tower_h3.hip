@@ -64,3 +64,30 @@ extern "C" int yy_nn_tower_heads_f16x3(const float *planes, const void *weights,
     return launch_h3(planes, weights, bias, nullptr, out_heads, rows, n_rows, G, R, C, channels, n_layers, weight_exp, head_exp,
                      act_exp, s);
 }
+
+// Small live batches (8x8).  With leaf-row compaction the number of rows a launch really computes is only known on the device,
+// and below ~320 rows the one-board-per-workgroup LDS-ring form is the faster one (232 us against 312 us for <= 128 rows: twice
+// as many CUs at work), above it the two-board register-ring form.  Both are launched with a gate on *n_rows -- the form that
+// is not wanted exits at once -- and write the same bits, so the choice never shows in the results.
+//   weights_lds = network.pack_tower_h3 (+ head chunks), weights_regs / head_w_regs = pack_tower_h3r / pack_heads_h3r.
+extern "C" int yy_tower_h3q_launch81_gated(const float *planes, const void *weights, const float *bias, float *out_heads,
+                                           const int *rows, const int *n_rows, int G, int n_layers, const float *sc,
+                                           int gate_lo, int gate_hi, yy_stream_t s);
+extern "C" int yy_tower_h3r_launch8_gated(const float *planes, const void *weights, const void *head_w, const float *bias,
+                                          float *out_heads, const int *rows, const int *n_rows, int G, int n_layers,
+                                          const float *sc, int gate_lo, int gate_hi, yy_stream_t s);
+
+extern "C" int yy_nn_tower_heads_f16x3_auto(const float *planes, const void *weights_lds, const void *weights_regs,
+                                            const void *head_w_regs, const float *bias, float *out_heads, const int32_t *rows,
+                                            const int32_t *n_rows, int G, int R, int C, int channels, int n_layers,
+                                            int weight_exp, int head_exp, int act_exp, int split, yy_stream_t s) {
+    if (G == 0) return YY_OK;
+    if (!planes || !weights_lds || !weights_regs || !head_w_regs || !bias || !out_heads || !rows || !n_rows || G < 0 || split < 0)
+        return yy_tower_set_err(YY_E_INVALID, "yy_nn_tower_heads_f16x3_auto: bad argument");
+    if (R != 8 || C != 8 || channels != 128 || n_layers < 1 || n_layers > 21 || (n_layers & 1) == 0)
+        return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_heads_f16x3_auto: 8x8 boards, 128 channels, at most 10 residual blocks");
+    const float sc[4] = {ldexpf(1.0f, act_exp), ldexpf(1.0f, -weight_exp), ldexpf(1.0f, -(head_exp + act_exp)), ldexpf(1.0f, -act_exp)};
+    if (int e = yy_tower_h3q_launch81_gated(planes, weights_lds, bias, out_heads, rows, n_rows, G, n_layers, sc, -1, split, s)) return e;
+    return yy_tower_h3r_launch8_gated(planes, weights_regs, head_w_regs, bias, out_heads, rows, n_rows, G, n_layers, sc, split,
+                                      0x7FFFFFFF, s);
+}

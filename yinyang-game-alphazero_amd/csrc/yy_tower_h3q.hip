@@ -211,11 +211,12 @@ __global__ void __launch_bounds__(256, 1)
 k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const float *__restrict__ bias,
             float *__restrict__ out, float *__restrict__ out_heads, const int *__restrict__ rows,
             const int *__restrict__ n_rows, int G, int n_layers, float in_scale, float acc_scale, float head_scale,
-            float out_scale) {
+            float out_scale, int gate_lo, int gate_hi) {
     using GEO = Geo<R_, TB_, NSLOT_>;
     constexpr int CT = GEO::CT, CELLS = GEO::CELLS, NCOL = GEO::NCOL, TB = GEO::TB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GEO::LDS_BYTES];
     const int n_live = n_rows ? min(*n_rows, G) : G;
+    if (n_live <= gate_lo || n_live > gate_hi) return;     // see yy_nn_tower_heads_f16x3_auto
     const int g0 = blockIdx.x * TB;                        // first dense row of the workgroup
     if (g0 >= n_live) return;                              // whole workgroup, before any barrier
     const int lane = threadIdx.x & 63;
@@ -365,9 +366,11 @@ k_tower_h3q(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
 template <int R_, int TB_, int NSLOT_>
 static int launch_hq(const float *planes, const void *weights, const float *bias, float *out, float *out_heads, const int *rows,
-                     const int *n_rows, int G, int n_layers, const float *sc, yy_stream_t s) {
+                     const int *n_rows, int G, int n_layers, const float *sc, yy_stream_t s, int gate_lo = -1,
+                     int gate_hi = 0x7FFFFFFF) {
     thq::k_tower_h3q<R_, TB_, NSLOT_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
-        planes, (const unsigned char *)weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc[0], sc[1], sc[2], sc[3]);
+        planes, (const unsigned char *)weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc[0], sc[1], sc[2], sc[3],
+        gate_lo, gate_hi);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3: launch failed");
     return YY_OK;
 }
@@ -385,4 +388,12 @@ extern "C" int yy_tower_h3q_launch(const float *planes, const void *weights, con
         return launch_hq<8, 2, 5>(planes, weights, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     }
     return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: board size");
+}
+
+// 8x8, one board per workgroup, with a device-side gate on the live row count (yy_nn_tower_heads_f16x3_auto)
+extern "C" int yy_tower_h3q_launch81_gated(const float *planes, const void *weights, const float *bias, float *out_heads,
+                                           const int *rows, const int *n_rows, int G, int n_layers, const float *sc,
+                                           int gate_lo, int gate_hi, yy_stream_t s) {
+    if (n_layers + 1 > HQ_MAX_LAYERS) return yy_tower_set_err(YY_E_UNSUPPORTED, "yy_nn_tower_f16x3: too many layers");
+    return launch_hq<8, 1, 5>(planes, weights, bias, nullptr, out_heads, rows, n_rows, G, n_layers, sc, s, gate_lo, gate_hi);
 }

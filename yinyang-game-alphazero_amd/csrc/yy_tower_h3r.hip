@@ -215,11 +215,12 @@ __global__ void __launch_bounds__(256, 1)
 k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ weights, const unsigned char *__restrict__ head_w,
             const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ out_heads,
             const int *__restrict__ rows, const int *__restrict__ n_rows, int G, int n_layers, float in_scale,
-            float acc_scale, float head_scale, float out_scale) {
+            float acc_scale, float head_scale, float out_scale, int gate_lo, int gate_hi) {
     using GEO = Geo<R_, TB_, D_, NV_>;
     constexpr int CT = GEO::CT, CELLS = GEO::CELLS, NCOL = GEO::NCOL, TB = GEO::TB, D = GEO::D;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GEO::LDS_BYTES];
     const int n_live = n_rows ? min(*n_rows, G) : G;
+    if (n_live <= gate_lo || n_live > gate_hi) return;     // the launch only runs for row counts in (gate_lo, gate_hi]: see yy_nn_tower_heads_f16x3_auto
     const int g0 = blockIdx.x * TB;                        // first dense row of the workgroup
     if (g0 >= n_live) return;                              // whole workgroup, before any barrier
     const int lane = threadIdx.x & 63;
@@ -376,10 +377,11 @@ k_tower_h3r(const float *__restrict__ planes, const unsigned char *__restrict__ 
 
 template <int R_, int TB_, int D_, int NV_>
 static int launch_hr(const float *planes, const void *weights, const void *head_w, const float *bias, float *out, float *out_heads,
-                     const int *rows, const int *n_rows, int G, int n_layers, const float (&sc)[4], yy_stream_t s) {
+                     const int *rows, const int *n_rows, int G, int n_layers, const float (&sc)[4], yy_stream_t s,
+                     int gate_lo = -1, int gate_hi = 0x7FFFFFFF) {
     thr::k_tower_h3r<R_, TB_, D_, NV_><<<dim3((G + TB_ - 1) / TB_), dim3(256), 0, (hipStream_t)s>>>(
         planes, (const unsigned char *)weights, (const unsigned char *)head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc[0],
-        sc[1], sc[2], sc[3]);
+        sc[1], sc[2], sc[3], gate_lo, gate_hi);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_tower_f16x3_regs: launch failed");
     return YY_OK;
 }
@@ -401,4 +403,12 @@ extern "C" int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, 
     if (R == 8) return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     if (R == 6) return launch_hr<6, 4, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     return launch_hr<12, 1, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
+}
+
+// 8x8 form with a device-side gate on the live row count (yy_tower_h3.hip: yy_nn_tower_heads_f16x3_auto)
+extern "C" int yy_tower_h3r_launch8_gated(const float *planes, const void *weights, const void *head_w, const float *bias,
+                                          float *out_heads, const int *rows, const int *n_rows, int G, int n_layers,
+                                          const float *sc, int gate_lo, int gate_hi, yy_stream_t s) {
+    const float scl[4] = {sc[0], sc[1], sc[2], sc[3]};
+    return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, nullptr, out_heads, rows, n_rows, G, n_layers, scl, s, gate_lo, gate_hi);
 }

@@ -231,6 +231,28 @@ def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, exps, rows=
     return out
 
 
+def tower_heads_forward_h3_auto(planes, weights_lds, weights_regs, head_w_regs, bias, n_layers, exps, rows, n_rows, split=320,
+                                out=None):
+    """8x8: tower_heads_forward_h3 / _h3r on the compacted rows with the kernel form chosen on the device from n_rows (at most
+    `split` live rows: one board per workgroup; more: two boards per workgroup, register ring).  Same bits either way."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
+    _need(weights_lds, torch.int16, (9 + 36 * (n_layers - 1) + 2, 8192), "split-f16 tower+heads weights")
+    _need(weights_regs, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
+    _need(head_w_regs, torch.int16, (2, 8192), "wave-major split-f16 head weights")
+    _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
+    _need(rows, torch.int32, (G,), "rows")
+    _need(n_rows, torch.int32, (1,), "n_rows")
+    if out is None:
+        out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
+    _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_heads_f16x3_auto(_p(planes), _p(weights_lds), _p(weights_regs), _p(head_w_regs), _p(bias), _p(out),
+                                                 _p(rows), _p(n_rows), G, R, Cc, 128, n_layers, int(exps[0]), int(exps[1]),
+                                                 int(exps[2]), int(split), _stream()))
+    return out
+
+
 def tower_forward_h3r(planes, weights, bias, n_layers, exps):
     """Tower activations f32 [G,128,R,R] (channels-last memory) from the register-ring kernel (tests)."""
     G, _, R, Cc = planes.shape

@@ -18,6 +18,8 @@ import torch.nn.functional as F
 
 H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
 H3R_MIN_ROWS = 256         # above this many rows the 8x8 split-f16 evaluator uses the register-ring kernel (yy_tower_h3r.hip)
+H3_AUTO_MAX_ROWS = 2048          # 8x8 batches up to this size launch both f16x3 forms, gated on the live row count (engine.tower_heads_forward_h3_auto)
+H3_AUTO_SPLIT = 320              # live rows: <= one board per workgroup (LDS ring), > two boards per workgroup (register ring)
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
 INPUT_PLANES = 5
@@ -353,6 +355,7 @@ class BatchedEvaluator:
             self.h3r_w = pack_tower_h3r(net)[0].to(self.device)
             self.h3r_hw = pack_heads_h3r(net)[0].to(self.device)
             self.h3r_min_rows = H3R_MIN_ROWS if tuple(net.board_size) == (8, 8) else 0
+            self.auto_form = tuple(net.board_size) == (8, 8)
             f32 = lambda t: t.detach().float().contiguous().to(self.device)
             self.pfc_wt, self.pfc_b = f32(net.policy_fc.weight.t()), f32(net.policy_fc.bias)
             self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
@@ -461,7 +464,11 @@ class BatchedEvaluator:
                 rows, n = engine.compact_rows(needs_eval, rows, n)
             else:
                 rows = n = None
-            if planes.shape[0] > self.h3r_min_rows and self.use_h3r:
+            if rows is not None and self.auto_form and self.h3r_min_rows < planes.shape[0] <= H3_AUTO_MAX_ROWS and self.use_h3r:
+                # a mid-size batch whose compacted launches may hold few rows: the form is chosen on the device per launch
+                feats = engine.tower_heads_forward_h3_auto(planes, self.h3_w, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers,
+                                                           self.h3_exps, rows, n, H3_AUTO_SPLIT)
+            elif planes.shape[0] > self.h3r_min_rows and self.use_h3r:
                 feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, self.h3_exps, rows, n)
             else:
                 feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, self.h3_exps, rows, n)   # [G, 2, 32*cells] f32
