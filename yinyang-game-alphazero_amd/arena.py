@@ -40,6 +40,10 @@ class DualEvaluator:
         self.sel = torch.ones(G, dtype=torch.bool, device=device)
         self.policy = torch.zeros((G, A), dtype=torch.float32, device=device)
         self.value = torch.zeros(G, dtype=torch.float32, device=device)
+        # dense mode with two compacting evaluators: the step's needs_eval flags go to both, so a step in which no game needs an
+        # evaluation (terminal revisits, reused evaluations) launches two towers that exit at once
+        self.supports_compaction = dense and all(getattr(e, "supports_compaction", False) for e in (ev_a, ev_b))
+        self.row_independent = all(getattr(e, "row_independent", False) for e in (ev_a, ev_b))
 
     def assign(self, a_rows):
         self.sel.copy_(a_rows)
@@ -47,8 +51,9 @@ class DualEvaluator:
             self.idx_a = a_rows.nonzero(as_tuple=True)[0]
             self.idx_b = (~a_rows).nonzero(as_tuple=True)[0]
 
-    def __call__(self, planes):
+    def __call__(self, planes, needs_eval=None):
         if self.dense:
+            kw = {} if needs_eval is None else dict(needs_eval=needs_eval)
             # the two forwards are independent and each fills only a few CUs: fork B onto a side stream (capturable),
             # join before the row select
             cur = torch.cuda.current_stream(planes.device)
@@ -56,8 +61,8 @@ class DualEvaluator:
                 self.side = torch.cuda.Stream(device=planes.device)
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                pb, vb = self.ev_b(planes)
-            pa, va = self.ev_a(planes)
+                pb, vb = self.ev_b(planes, **kw)
+            pa, va = self.ev_a(planes, **kw)
             cur.wait_stream(self.side)
             torch.where(self.sel[:, None], pa, pb, out=self.policy)
             torch.where(self.sel, va, vb, out=self.value)
@@ -93,8 +98,10 @@ class Arena:
     between two fixed networks is deterministic, as the reference's is."""
 
     def __init__(self, game, player_a, player_b, num_simulations=800, cpuct=1.0, device=None, seed=0,
-                 reference_scoring=False, literal=False):
-        """reference_scoring=True reproduces the reference's attribution literally (alphazero.py:206-218): the value of
+                 reference_scoring=False, literal=False, evaluation_reuse=True):
+        """evaluation_reuse: inside one search a position is evaluated once (pass values, other move orders) when both players
+        are row-independent compacting evaluators (the float32-accurate BatchedEvaluator); the moves are the same.
+        reference_scoring=True reproduces the reference's attribution literally (alphazero.py:206-218): the value of
         getGameEnded for the player who would move NEXT is read as "+1 = first player won, -1 = second player won".
         literal=True reproduces the whole reference match loop (alphazero.py:171-220): the search runs on the game's own
         board object and mutates it (aliased boards), there is no pass handling -- a side without a move still
@@ -102,6 +109,7 @@ class Arena:
         and the scoring is the reference's."""
         self.game = game
         self.literal = bool(literal)
+        self.evaluation_reuse = bool(evaluation_reuse)
         self.reference_scoring = bool(reference_scoring) or self.literal
         self.R, self.C = game.getBoardSize()
         self.A = self.R * self.C
@@ -125,8 +133,11 @@ class Arena:
         ev_b = _uniform_evaluator(self.A) if self.pb == "random" else self.pb
         dense = G <= 1024
         dual = DualEvaluator(ev_a, ev_b, G, self.A, dev, dense=dense)
+        # a search uses ONE network per game (assigned per move), so inside a search a position's evaluation can be reused
+        # (pass values, other move orders); never across searches: the two networks alternate
+        reuse = self.evaluation_reuse and (not self.literal) and dense and dual.supports_compaction and dual.row_independent
         ctx = engine.BatchedMCTS(G, self.R, self.C, max(1, self.sims), cpuct=self.cpuct, rowcol=self.rowcol, device=dev,
-                                 aliased=self.literal)
+                                 aliased=self.literal, reuse_pass_value=reuse, reuse_transpositions=reuse)
         try:
             search = LockstepSearch(ctx, dual, use_graph=dense)     # routed mode: the row sets change every move
             result = torch.zeros(G, dtype=torch.int8, device=dev)   # +1 black won, -1 white won, 2 draw
