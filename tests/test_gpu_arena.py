@@ -140,7 +140,7 @@ def test_alphazero_iteration_at_config5_size(tmp_path):
 
 
 def test_arena_with_evaluation_reuse_plays_the_same_match():
-    """Two different 128x2 networks, the float32-accurate evaluator, 8x8, 12 games of 96 simulations: with the arena's
+    """Two different 128x2 networks, the float32-accurate evaluator, 8x8, 6 games of 800 simulations: with the arena's
     within-search evaluation reuse (pass values + positions reached by another move order; never across searches, the two
     networks alternate) every move of every game and the result are the same as without it."""
     import time
@@ -153,16 +153,16 @@ def test_arena_with_evaluation_reuse_plays_the_same_match():
         evs.append(pkg.BatchedEvaluator(pkg.YinYangNeuralNetwork(game, 128, 2).cuda().eval()))
     out = []
     for reuse in (True, False):
-        arena = pkg.Arena(game, evs[0], evs[1], num_simulations=96, evaluation_reuse=reuse)
+        arena = pkg.Arena(game, evs[0], evs[1], num_simulations=800, evaluation_reuse=reuse)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = arena.play(12, record=True)
+        res = arena.play(6, record=True)
         torch.cuda.synchronize()
         out.append((res, arena.transcript, time.perf_counter() - t0))
     (r1, t1, s1), (r0, t0_, s0) = out
-    assert r1 == r0 and r1["games"] == 12
+    assert r1 == r0 and r1["games"] == 6
     for k in t1:
         assert np.array_equal(t1[k], t0_[k]), k
-    print("arena 12 games x 96 sims: %.2f s with evaluation reuse, %.2f s without" % (s1, s0))
+    print("arena 6 games x 800 sims: %.2f s with evaluation reuse, %.2f s without" % (s1, s0))
 
 
 def test_alphazero_player_api():
