@@ -341,14 +341,15 @@ def gen_g3(sizes, pool):
 
 
 def _search_net_case(args):
-    R, C, seed, sims, copied, noise = args
+    R, C, seed, sims, copied, noise = args[:6]
+    net_shape = args[6] if len(args) > 6 else None          # (num_channels, num_res_blocks); None = the default 128 x 10
     import torch
     YinYangGame, YinYangLogic, MCTS = _import_ref()
     from src.yin_yang.ai.neural_network import YinYangNeuralNetwork
     torch.manual_seed(0)
     torch.set_num_threads(1)
     plain = YinYangGame(R, C)
-    net = YinYangNeuralNetwork(plain)          # default 128 x 10
+    net = YinYangNeuralNetwork(plain) if net_shape is None else YinYangNeuralNetwork(plain, *net_shape)   # default 128 x 10
     Game = make_copied_game(YinYangGame) if copied else YinYangGame
     game = Game(R, C)
     rng = np.random.default_rng(seed)
@@ -405,9 +406,9 @@ def gen_g3_net(pool):
 def _search_net800_case(args):
     """One 800-simulation search with the real seeded 128x10 net (CPU fp32, as the reference runs it): only the RESULTS are
     kept (pi, counts, child statistics, root value sum, the root evaluation) -- the live GPU evaluators are compared with these."""
-    R, C, seed, sims, copied, noise, root_player = args
-    r = _search_net_case((R, C, seed, sims, copied, noise)) if root_player == 1 else None
-    assert r is not None
+    R, C, seed, sims, copied, noise, root_player = args[:7]
+    assert root_player == 1
+    r = _search_net_case((R, C, seed, sims, copied, noise) + tuple(args[7:]))
     out = {k: v for k, v in r.items() if not k.startswith("rec_")}
     out["root_policy"] = r["rec_policy"][0]
     out["root_value"] = r["rec_value"][0]
@@ -426,6 +427,33 @@ def gen_g3_net800(pool):
     path = os.path.join(OUT, "search_net800_8x8.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(res), "cases", flush=True)
+
+
+# (file tag, R, C, sims, roots, first seed, net shape): BASELINE configs 4 and 1 with the default 128 x 10 net, and shapes the
+# generalised split-f16 tower must cover (non-square boards, other widths / depths: train_alphazero.py:35-36, neural_network.py:39)
+NET_SEARCH_SETS = {
+    "net1600_12x12": (12, 12, 1600, 24, 3000, None),
+    "net800_6x6": (6, 6, 800, 32, 4000, None),
+    "net25_6x6": (6, 6, 25, 32, 4100, None),
+    "net400_10x10_c64b4": (10, 10, 400, 16, 5000, (64, 4)),
+    "net400_5x7_c96b3": (5, 7, 400, 16, 5100, (96, 3)),
+    "net200_9x12_c32b2": (9, 12, 200, 16, 5200, (32, 2)),
+}
+
+
+def gen_g3_net_sets(pool, names):
+    """search_<tag>.npz: the reference's MCTS.search with its own CPU float32 network (seeded random init) at the other BASELINE
+    sizes -- roots = the empty board (even seeds) and random legal-play positions at random plies (odd seeds), both board
+    semantics, with and without root noise; results only (ai/mcts.py:275-343 with ai/neural_network.py:125-154)."""
+    for name in names:
+        R, C, sims, n, seed0, shape = NET_SEARCH_SETS[name]
+        jobs = [(R, C, seed0 + k, sims, k % 2, (k // 2) % 2, 1) + ((shape,) if shape else ()) for k in range(n)]
+        res = pool.map(_search_net800_case, jobs, chunksize=1)
+        out = {k: np.stack([np.asarray(r[k]) for r in res]) for k in res[0]}
+        out["net_shape"] = np.asarray(shape if shape else (128, 10), np.int32)
+        path = os.path.join(OUT, "search_%s.npz" % name)
+        np.savez_compressed(path, **out)
+        print("wrote", path, len(res), "cases", flush=True)
 
 
 # --------------------------------------------------------------------------- row/column rule (browser JS only)
@@ -909,6 +937,9 @@ def main():
         gen_rowcol()
     if "g3net800" in only:
         gen_g3_net800(pool)
+    sets = [k for k in NET_SEARCH_SETS if k in only or "netsets" in only]
+    if sets:
+        gen_g3_net_sets(pool, sets)
     if "g4" in only:
         gen_g4(pool)
     if "g6" in only:
