@@ -35,8 +35,9 @@ import torch
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: bf16 / f16 MFMA ~2.5 PFLOP/s dense
 MFMA_F32_PEAK_TFLOPS = 157.3    # same guide: f32-input MFMA = the f32 vector rate
-NN_MODES = ["f16x3", "bf16", "fp16", "fp32", "fp32t", "bf16x3"]
+NN_MODES = ["f16x3", "f16x3r", "bf16", "fp16", "fp32", "fp32t"]
 FP32_GRADE = {"f16x3": "float32-accurate split-f16 MFMA (hi + lo float16 pairs = 22 significant bits, f32 accumulate)",
+              "f16x3r": "float32-accurate split-f16 MFMA, round-2 32x32x16 tower kernel (A/B partner)",
               "fp32t": "exact float32 MFMA", "fp32": "float32 (PyTorch/MIOpen)"}
 
 
@@ -165,23 +166,27 @@ def tower_launcher(eng):
     mode = getattr(ev, "mode", "")
     planes = eng.ctx.planes
     if mode == "f16x3":
-        form = {8: "k_tower_h3r<8,2,9> (two boards per workgroup, wave = output-channel quarter, weight stream in registers)",
-                6: "k_tower_h3r<6,4,3>", 12: "k_tower_h3r<12,1,3>"}[eng.R]
-        regs = G > ev.h3r_min_rows
+        stem = 2 * 9 * 5 * ev.net.conv1.out_channels * cells
+        ch = ev.net.conv1.out_channels
+        body = 2 * blocks * (2 * 9 * ch * ch * cells)
+        heads = 2 * ch * 64 * cells
+        if ev.use_h3r:
+            form = {8: "k_tower_h3r<8,2,9>", 6: "k_tower_h3r<6,4,3>", 12: "k_tower_h3r<12,1,3>"}[eng.R] + " (round-2 32x32x16 kernel, A/B partner)"
 
-        def launch(rows=None, n_rows=None):
-            if regs:
+            def launch(rows=None, n_rows=None):
                 return E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n_rows)
-            return E.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n_rows)
+        else:
+            nb, tb = ev.g_big if G > ev.g_split else ev.g_small
+            form = "k_tower_g<%d,%d,9> (%d boards = %d of %d columns per workgroup, v_mfma_f32_16x16x32_f16, wave = 32 output channels, weight stream in registers)" % (
+                ch // 32, nb, tb, tb * cells, 16 * nb)
+
+            def launch(rows=None, n_rows=None):
+                return E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb, ev.g_hw, ev.g_hb, rows, n_rows)
         return (launch,
                 form + ": stem + residual tower + 1x1 head convs, split-f16 (3 f16 MFMAs per product term, float32-accurate); "
-                       "peak = f16 MFMA dense peak / 3 (nominal, 2.4 GHz; hipBLASLt's dense f16 GEMM sustains 0.53 of nominal on "
-                       "this board under its power management: profiles/r02_power_probe.json)",
-                (2 * 9 * 5 * 128 * cells + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
-    if mode == "bf16x3":
-        return (lambda: E.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers),
-                "k_tower_x3: stem + residual tower, split-bf16 (3 bf16 MFMAs per product term); peak = bf16 MFMA peak / 3",
-                (2 * 9 * 16 * 128 * cells + body) * G, MFMA_BF16_PEAK_TFLOPS / 3)
+                       "peak = f16 MFMA dense peak / 3 (nominal, 2.4 GHz; what this board sustains for bare f16 MFMA issue on random "
+                       "operands: profiles/r03_mfma_ceiling.json)",
+                (stem + body + heads) * G, MFMA_BF16_PEAK_TFLOPS / 3)
     if mode == "fp32t":
         return (lambda: E.tower_forward_f32(planes, ev.f32_w, ev.f32_b, ev.f32_layers),
                 "k_tower_f32: stem + residual tower, exact f32 MFMA 32x32x2", (2 * 9 * 8 * 128 * cells + body) * G,

@@ -245,60 +245,59 @@ int yy_nn_tower_heads_bf16(const float *planes, const void *weights, const float
 int yy_nn_tower_f32(const float *planes, const void *weights, const float *bias, float *out, int G,
                     int R, int C, int channels, int n_layers, yy_stream_t stream);
 
-/* The residual tower at float32-grade accuracy on the BF16 matrix cores: activations and weights are (hi, lo) bf16
- * pairs (16 mantissa bits), each product is w_hi*x_hi + w_hi*x_lo + w_lo*x_hi on v_mfma_f32_32x32x16_bf16 into one f32
- * accumulator; bias / residual / ReLU in f32.  Same I/O as yy_nn_tower_f32; weights = bf16 chunks
- * [9 + 36*(n_layers-1)][8192] from network.pack_tower_x3.  8x8 boards, 128 channels.  Replaces the same reference
- * code as yy_nn_tower_f32 (neural_network.py:94-110). */
-int yy_nn_tower_bf16x3(const float *planes, const void *weights, const float *bias, float *out, int G,
-                       int R, int C, int channels, int n_layers, yy_stream_t stream);
-
 /* Head finish (neural_network.py:115, 120-121, 152): h bf16 [G, A+H] = policy logits then value_fc1
  * outputs (bias added); policy float32 [G,A] = softmax(logits); value float32 [G] =
  * tanh(relu(hidden) . w2 + b2) with w2 float32 [H], b2 float32 [1]. */
 int yy_nn_head_finish_bf16(const void *h, int G, int A, int H, const float *w2, const float *b2,
                            float *policy, float *value, yy_stream_t stream);
 
-/* The residual tower at FLOAT32 accuracy on the F16 matrix cores ("split-f16"; csrc/yy_tower_h3.hip): activations and
- * weights are held as hi = f16(x), lo = f16(x - hi) (22 significant bits), each product is w_lo*x_hi + w_hi*x_lo + w_hi*x_hi
- * on v_mfma_f32_32x32x16_f16 into one f32 accumulator; bias / residual / ReLU in f32.  To keep the lo parts in float16's
- * normal range the weights are stored times 2^weight_exp and the activations (and the bias rows of the tower) live times
- * 2^act_exp -- exact scalings chosen by network.pack_tower_h3.  Agrees with a float64 evaluation to ~4e-7 of scale, like the
- * float32 module itself.  Same I/O as yy_nn_tower_f32; weights = f16 chunks [9 + 36*(n_layers-1)][8192].  Boards 6x6, 8x8,
- * 12x12, 128 channels.  Replaces ai/neural_network.py:94-110 (float32 on the CPU in the reference). */
-int yy_nn_tower_f16x3(const float *planes, const void *weights, const float *bias, float *out, int G,
-                      int R, int C, int channels, int n_layers, int weight_exp, int act_exp,
-                      yy_stream_t stream);
-
-/* Same + the policy_conv / value_conv 1x1 head convolutions, BatchNorm and ReLU (neural_network.py:113, 118):
- * out_heads float32 [G,2,32,R*R] = [policy features, value features] in the reference's NCHW flatten order (:114 / :119).
- * weights holds two more chunks (times 2^head_exp) and bias one more, unscaled, row (network.pack_heads_h3).  rows / n_rows
- * (device pointers, or both NULL): evaluate planes[rows[i]] for i < *n_rows into out_heads row i; workgroups past *n_rows
- * exit at once. */
-int yy_nn_tower_heads_f16x3(const float *planes, const void *weights, const float *bias, float *out_heads,
-                            const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
-                            int channels, int n_layers, int weight_exp, int head_exp, int act_exp,
-                            yy_stream_t stream);
-
-/* The same evaluator with the weight stream held in REGISTERS (yy_tower_h3r.hip; the form the engine uses): every wave loads
- * the fragments of its own output-channel quarter global -> register, up to nine 16 KB chunks ahead, instead of staging
- * weights through LDS.  weights / head_w in the wave-major order of network.pack_tower_h3r / pack_heads_h3r; exactly one of out
- * (float32 [G,R,R,128] tower activations) and out_heads (float32 [G,2,32,R*R], needs head_w) is non-NULL; rows / n_rows and the
- * exponents as above.  Identical bits to yy_nn_tower_f16x3 / yy_nn_tower_heads_f16x3. */
+/* The residual tower at FLOAT32 accuracy on the F16 matrix cores ("split-f16"): activations and weights are held as
+ * hi = f16(x), lo = f16(x - hi) (22 significant bits); per output element one f32 accumulator takes w_hi*x_hi and a second
+ * one w_lo*x_hi + w_hi*x_lo; bias / residual / ReLU in f32.  To keep the lo parts in float16's normal range the weights are
+ * stored times 2^weight_exp and the activations (and the bias rows of the tower) live times 2^act_exp -- exact scalings chosen
+ * by the packers in network.py.  Agrees with a float64 evaluation to ~5e-7 of scale, like the float32 module itself.
+ * Replaces ai/neural_network.py:94-119 (float32 on the CPU in the reference).
+ *
+ * yy_nn_tower_f16x3_regs = the round-2 form (csrc/yy_tower_h3r.hip: v_mfma_f32_32x32x16_f16, boards 6x6 / 8x8 / 12x12,
+ * 128 channels), kept as the A/B partner of yy_nn_tower_g below: weights / head_w in the wave-major order of
+ * network.pack_tower_h3r / pack_heads_h3r ([9 + 36*(n_layers-1)][8192] / [2][8192] f16); bias float32 [n_layers (+1), 128];
+ * exactly one of out (float32 [G,R,R,128] tower activations) and out_heads (float32 [G,2,32,R*R] = [policy features, value
+ * features] in the reference's NCHW flatten order, neural_network.py:114 / :119; needs head_w) is non-NULL; rows / n_rows
+ * (device pointers, or both NULL): evaluate planes[rows[i]] for i < *n_rows into dense row i, workgroups past *n_rows exit. */
 int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, const void *head_w, const float *bias,
                            float *out, float *out_heads, const int32_t *rows, const int32_t *n_rows, int G,
                            int R, int C, int channels, int n_layers, int weight_exp, int head_exp,
                            int act_exp, yy_stream_t stream);
 
-/* 8x8 only: the same tower + head convolutions on the compacted rows (rows / n_rows as above, both required), with the kernel
- * form chosen ON THE DEVICE from *n_rows: at most `split` live rows -> one board per workgroup with the LDS weight ring (twice
- * as many CUs busy while the chip is not full), more -> two boards per workgroup with the register ring.  Both forms are
- * launched, each gated on *n_rows; they write identical bits.  weights_lds as for yy_nn_tower_heads_f16x3, weights_regs /
- * head_w_regs as for yy_nn_tower_f16x3_regs. */
-int yy_nn_tower_heads_f16x3_auto(const float *planes, const void *weights_lds, const void *weights_regs,
-                                 const void *head_w_regs, const float *bias, float *out_heads, const int32_t *rows,
-                                 const int32_t *n_rows, int G, int R, int C, int channels, int n_layers, int weight_exp,
-                                 int head_exp, int act_exp, int split, yy_stream_t stream);
+/* The GENERAL form of the float32-accurate tower (csrc/yy_tower_g.hip; the form the engine uses): any R x C board with at
+ * most 144 cells (train_alphazero.py:35-36 takes any --rows / --cols), 32 / 64 / 96 / 128 channels and up to 10 residual
+ * blocks (ai/neural_network.py:39), on v_mfma_f32_16x16x32_f16: a workgroup of channels/32 waves evaluates `boards` boards =
+ * nb blocks of 16 (board, cell) columns (boards * R * C <= 16 * nb; nb one of yy_nn_tower_g_forms).  Same split-f16 numerics
+ * and the same I/O conventions as yy_nn_tower_f16x3_regs: weights = f16 chunks [9 + 9*(channels/32)*(n_layers-1)]
+ * [channels*64] in MFMA operand order (network.pack_tower_g) times 2^weight_exp; bias float32 [n_layers, channels] times
+ * 2^act_exp; exactly one of out (float32 [G,R,C,channels]) and out_heads (float32 [G,2,32,R*C]: needs head_w = f16
+ * [4][channels/32][2][512] times 2^head_exp and head_bias float32 [64], network.pack_heads_g) is non-NULL; rows / n_rows as
+ * above.  The launch only computes when gate_lo < live rows <= gate_hi (-1, INT_MAX: always), so that two forms can be
+ * enqueued and the one fitting the device-side row count runs.  A row's results do not depend on nb, boards or its position
+ * in the batch (same accumulation order per output element in every form).  Replaces ai/neural_network.py:94-119. */
+int yy_nn_tower_g(const float *planes, const void *weights, const void *head_w, const float *bias, const float *head_bias,
+                  float *out, float *out_heads, const int32_t *rows, const int32_t *n_rows, int G, int R, int C,
+                  int channels, int n_layers, int weight_exp, int head_exp, int act_exp, int nb, int boards, int gate_lo,
+                  int gate_hi, yy_stream_t stream);
+/* the nb values yy_nn_tower_g is built for at this channel count: writes up to 8 ints, returns how many (0: unsupported) */
+int yy_nn_tower_g_forms(int channels, int *nb_out);
+
+/* policy_fc and value_fc1 (neural_network.py:115, :120; float32 on the CPU in the reference) as one split-f16 GEMM kernel of
+ * our own (csrc/yy_fc_heads.hip), on the dense feature rows a tower launch wrote: feats float32 [G,2,K] (K = 32*R*C) ->
+ * logits float32 [G,A] = policy_fc(feats[:,0]), hidden float32 [G,H] = value_fc1(feats[:,1]), bias added.  wpk / bias / jobs
+ * from network.pack_fc_heads: jobs int32 [n_jobs][4] = (head, first output, outputs <= 64, first 8 KB weight block), weights f16
+ * [n_jobs][ceil(K/128)*4][4][2][64][8] times 2^weight_exp; features are split as x * 2^act_exp = hi + lo.  n_rows (device, or
+ * NULL = G): rows past *n_rows are neither read nor written.  Every output element is one fixed k-ascending MFMA chain (no
+ * split-K, no batch-size dependent tiling): a row's outputs do not depend on G, *n_rows or its position in the batch, which
+ * is what lets the search reuse evaluations across launches of different sizes (YY_FLAG_REUSE_*). */
+int yy_nn_fc_heads_f16x3(const float *feats, const void *wpk, const float *bias, const int32_t *jobs, int n_jobs,
+                         float *logits, float *hidden, const int32_t *n_rows, int G, int K, int A, int H,
+                         int weight_exp, int act_exp, yy_stream_t stream);
 
 /* float32 head finish (neural_network.py:115, 120-121, 152): logits float32 [G,A] (policy_fc output, bias added), hidden
  * float32 [G,H] (value_fc1 output, bias added) of dense row i -> policy[g] = softmax(logits[i]),

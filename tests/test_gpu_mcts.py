@@ -535,19 +535,36 @@ LIVE_BOUNDS = {
     "fp32":   (1e-5, 1e-5, 1.0),
     "fp32t":  (1e-5, 1e-5, 1.0),
     "f16x3":  (1e-5, 1e-5, 1.0),
-    "bf16x3": (None, None, 0.0),     # 16 significant bits: reported, not held to the bound
+    "f16x3r": (1e-5, 1e-5, 1.0),     # the round-2 32x32x16 tower kernel (A/B partner of the general kernel)
     "bf16":   (None, None, 0.0),     # 8 significant bits: reported
 }
 
 
-@pytest.mark.parametrize("mode", list(LIVE_BOUNDS))
-def test_live_gpu_evaluator_search_vs_reference_pi(pkg, mode):
+# (fixture, modes): the reference's own searches with its CPU float32 network (tests/golden/make_golden.py: NET_SEARCH_SETS) --
+# BASELINE config 2 (8x8 / 800), config 4 (12x12 / 1600), config 1 (6x6 / 25, plus 800), and three shapes outside the defaults
+# (non-square boards, 32 / 64 / 96 channels) that `--nn auto` must also run at reference precision.
+LIVE_SETS = [("net800_8x8", list(LIVE_BOUNDS)),
+             ("net1600_12x12", ["f16x3", "f16x3r", "fp32"]),
+             ("net800_6x6", ["f16x3", "f16x3r", "fp32"]),
+             ("net25_6x6", ["f16x3", "f16x3r", "fp32"]),
+             ("net400_10x10_c64b4", ["f16x3", "fp32"]),
+             ("net400_5x7_c96b3", ["f16x3", "fp32"]),
+             ("net200_9x12_c32b2", ["f16x3", "fp32"])]
+
+
+@pytest.mark.parametrize("name,mode", [(n, m) for n, ms in LIVE_SETS for m in ms])
+def test_live_gpu_evaluator_search_vs_reference_pi(pkg, name, mode):
     import json
     import torch
-    z = np.load(os.path.join(GOLDEN, "search_net800_8x8.npz"))
+    z = np.load(os.path.join(GOLDEN, "search_%s.npz" % name))
+    R, C = z["root_board"].shape[1:]
+    sims = int(z["sims"][0])
+    shape = tuple(int(x) for x in z["net_shape"]) if "net_shape" in z.files else (128, 10)
     torch.manual_seed(0)                                             # the generator's seed: same weights as the reference's net
-    game = pkg.YinYangGame(8, 8)
-    net = pkg.YinYangNeuralNetwork(game).cuda().eval()
+    game = pkg.YinYangGame(R, C)
+    net = pkg.YinYangNeuralNetwork(game, *shape).cuda().eval()
+    if mode == "f16x3":
+        assert pkg.BatchedEvaluator(net).mode == "f16x3"             # what `--nn auto` runs for this shape
     ev = pkg.BatchedEvaluator(net, mode)
     n = z["counts"].shape[0]
     dpi, dv, same = np.zeros(n), np.zeros(n), np.zeros(n, bool)
@@ -557,7 +574,7 @@ def test_live_gpu_evaluator_search_vs_reference_pi(pkg, mode):
     for copied in (0, 1):
         for has_noise in (0, 1):
             idx = np.flatnonzero((z["copied"] == copied) & (z["has_noise"] == has_noise))
-            mc = pkg.MCTS(game, ev, num_simulations=800, board_semantics="copied" if copied else "aliased")
+            mc = pkg.MCTS(game, ev, num_simulations=sims, board_semantics="copied" if copied else "aliased")
             boards = torch.from_numpy(z["root_board"][idx]).cuda()
             players = torch.ones(len(idx), dtype=torch.int8, device="cuda")
             noise = torch.from_numpy(z["noise"][idx]).cuda() if has_noise else None
@@ -565,19 +582,20 @@ def test_live_gpu_evaluator_search_vs_reference_pi(pkg, mode):
             counts = ctx.root_counts().cpu().numpy()
             visits, wsum = ctx.root_stats()
             ctx.status()
-            assert (visits.cpu().numpy() == 800).all()
+            assert (visits.cpu().numpy() == sims).all()
             dpi[idx] = np.abs(pi.cpu().numpy() - z["pi"][idx]).max(1)
-            dv[idx] = np.abs(wsum.cpu().numpy() - z["root_w"][idx]) / 800.0       # root value = value_sum / visits
+            dv[idx] = np.abs(wsum.cpu().numpy() - z["root_w"][idx]) / float(sims)       # root value = value_sum / visits
             same[idx] = (counts == z["counts"][idx]).all(1)
             mc.close()
-    rec = dict(mode=mode, roots=int(n), sims=800, identical_visit_counts=float(same.mean()), max_dpi=float(dpi.max()),
+    rec = dict(fixture=name, board="%dx%d" % (R, C), net="%dx%d" % shape, mode=mode, roots=int(n), sims=sims,
+               identical_visit_counts=float(same.mean()), max_dpi=float(dpi.max()),
                median_dpi=float(np.median(dpi)), max_dvalue=float(dv.max()), root_policy_err=e_root_p, root_value_err=e_root_v)
     print("live evaluator parity:", json.dumps(rec))
     out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
     os.makedirs(out, exist_ok=True)
     path = os.path.join(out, "live_eval_parity.json")
     allrec = json.load(open(path)) if os.path.exists(path) else {}
-    allrec[mode] = rec
+    allrec["%s/%s" % (name, mode)] = rec
     json.dump(allrec, open(path, "w"), indent=1)
     bpi, bv, frac = LIVE_BOUNDS[mode]
     assert same.mean() >= frac, rec

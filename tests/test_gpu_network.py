@@ -231,45 +231,6 @@ def test_f32_tower_kernel_matches_fp32_module():
         assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4
 
 
-def test_split_bf16_tower_kernel_matches_fp32_module():
-    """csrc/yy_tower_x3.hip (activations and weights as (hi, lo) bf16 pairs, three bf16 MFMAs per product term, f32
-    accumulation) against the fp32 nn.Module: 16 mantissa bits per operand, so activations within 1e-4 relative to the layer
-    scale (measured ~1e-5), policy 1e-5 / value 1e-4 abs -- the same bounds as the exact-f32 kernel."""
-    import torch
-    import yinyang_game_alphazero_amd as pkg
-    torch.manual_seed(2)
-    torch.backends.cudnn.allow_tf32 = False
-    game = pkg.YinYangGame(8, 8)
-    rng = np.random.default_rng(6)
-    for blocks, G in ((1, 3), (10, 71)):
-        net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
-        with torch.no_grad():
-            for m in net.modules():
-                if isinstance(m, torch.nn.BatchNorm2d):
-                    m.running_mean.normal_(0, 0.1)
-                    m.running_var.uniform_(0.5, 1.5)
-                    m.weight.uniform_(0.7, 1.3)
-                    m.bias.normal_(0, 0.1)
-                if isinstance(m, torch.nn.Conv2d):
-                    m.bias.normal_(0, 0.05)
-        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda()
-        planes = pkg.engine.encode_planes(boards)
-        ev = pkg.BatchedEvaluator(net, "bf16x3")
-        x_t = pkg.engine.tower_forward_x3(planes, ev.f32_w, ev.f32_b, ev.f32_layers)
-        with torch.no_grad():
-            x = torch.relu(net.bn1(net.conv1(planes)))
-            for blk in net.res_blocks:
-                x = blk(x)
-        scale = float(x.abs().max())
-        err = float((x_t - x).abs().max())
-        print("bf16x3 tower: blocks %d max|err| %.3e scale %.3e" % (blocks, err, scale))
-        assert err <= 1e-4 * scale, (blocks, err, scale)
-        p, v = ev(planes)
-        p32, v32 = pkg.BatchedEvaluator(net, "fp32")(planes)
-        print("bf16x3 evaluator: policy err %.3e value err %.3e" % (float((p - p32).abs().max()), float((v - v32).abs().max())))
-        assert float((p - p32).abs().max()) < 1e-5 and float((v - v32).abs().max()) < 1e-4
-
-
 def test_gpu_evaluators_against_reference_recorded_outputs():
     """The reference's own (board -> policy, value) pairs (search_net_8x8.npz, CPU fp32, seed 0) against the mirror on the
     GPU: fp32 module and the exact-f32 tower within 1e-5 on policy / 1e-4 on value; bf16 tower within 2e-2 / 5e-2."""
@@ -283,17 +244,17 @@ def test_gpu_evaluators_against_reference_recorded_outputs():
     boards = torch.from_numpy(z["rec_boards"][1, :n]).cuda()
     rp, rv = torch.from_numpy(z["rec_policy"][1, :n]).cuda(), torch.from_numpy(z["rec_value"][1, :n]).cuda()
     planes = pkg.engine.encode_planes(boards)
-    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("f16x3", 1e-5, 1e-5), ("bf16x3", 1e-5, 1e-4), ("bf16", 2e-2, 5e-2)):
+    for mode, tp, tv in (("fp32", 1e-5, 1e-4), ("fp32t", 1e-5, 1e-4), ("f16x3", 1e-5, 1e-5), ("f16x3r", 1e-5, 1e-5), ("bf16", 2e-2, 5e-2)):
         p, v = pkg.BatchedEvaluator(net, mode)(planes)
         ep, ev_ = float((p - rp).abs().max()), float((v - rv).abs().max())
         print("%s vs the reference's recorded outputs: policy %.3e value %.3e" % (mode, ep, ev_))
         assert ep < tp and ev_ < tv, mode
 
 
-def _randomized_net(pkg, game, blocks, seed):
+def _randomized_net(pkg, game, blocks, seed, channels=128):
     import torch
     torch.manual_seed(seed)
-    net = pkg.YinYangNeuralNetwork(game, 128, blocks).cuda().eval()
+    net = pkg.YinYangNeuralNetwork(game, channels, blocks).cuda().eval()
     with torch.no_grad():
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
@@ -320,24 +281,28 @@ def _module_f64(net, planes):
         return x, torch.softmax(logits, 1), value.reshape(-1)
 
 
-@pytest.mark.parametrize("R", [8, 6, 12])
-def test_split_f16_tower_kernel_is_float32_grade(R):
-    """csrc/yy_tower_h3*.hip (activations and weights as hi + lo float16 pairs, three f16 MFMAs per product term, two
-    f32 accumulators) against the module evaluated in FLOAT64: 22 significant bits per operand, so the error must be that
-    of float32 arithmetic itself.  Bounds: tower activations within 2e-6 of the layer scale (measured ~4e-7; the float32
-    module measures ~3e-7 on the same inputs), policy and value within 2e-6 abs (north-star: 1e-5)."""
+SPLIT_F16_SHAPES = [(8, 8, 128), (6, 6, 128), (12, 12, 128), (10, 10, 128), (5, 7, 96), (9, 12, 32), (7, 7, 64), (3, 3, 128), (1, 6, 64)]
+
+
+@pytest.mark.parametrize("R,C,ch", SPLIT_F16_SHAPES)
+def test_split_f16_tower_kernel_is_float32_grade(R, C, ch):
+    """csrc/yy_tower_g.hip (activations and weights as hi + lo float16 pairs, three f16 MFMAs per product term, two f32
+    accumulators) against the module evaluated in FLOAT64: 22 significant bits per operand, so the error must be that of
+    float32 arithmetic itself.  Square and non-square boards, every supported width (train_alphazero.py:35-36,
+    neural_network.py:39).  Bounds: tower activations within 2e-6 of the layer scale (measured ~5e-7; the float32 module
+    measures ~3e-7 on the same inputs), policy and value within 2e-6 abs (north-star: 1e-5)."""
     import torch
     import yinyang_game_alphazero_amd as pkg
     torch.backends.cudnn.allow_tf32 = False
-    game = pkg.YinYangGame(R, R)
+    game = pkg.YinYangGame(R, C)
     rng = np.random.default_rng(6)
-    for blocks, G in ((1, 3), (10, 71 if R == 8 else 23)):
-        net = _randomized_net(pkg, game, blocks, 2)
-        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda()
+    for blocks, G in ((1, 3), (10 if ch == 128 else 4, 71 if R * C <= 64 else 23)):
+        net = _randomized_net(pkg, game, blocks, 2, ch)
+        boards = torch.from_numpy(rng.integers(-1, 2, size=(G, R, C)).astype(np.int8)).cuda()
         planes = pkg.engine.encode_planes(boards)
-        ev = pkg.BatchedEvaluator(net, "f16x3")
-        n_tower = 9 + 36 * (ev.h3_layers - 1)
-        x_t = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), ev.h3_b[:ev.h3_layers].contiguous(), ev.h3_layers, ev.h3_exps)
+        ev = pkg.BatchedEvaluator(net)
+        assert ev.mode == "f16x3"                      # what --nn auto picks for every one of these shapes
+        x_t = pkg.engine.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, ev.g_big[0], ev.g_big[1])
         x64, p64, v64 = _module_f64(net, planes)
         scale = float(x64.abs().max())
         err = float((x_t.double() - x64).abs().max())
@@ -346,7 +311,7 @@ def test_split_f16_tower_kernel_is_float32_grade(R):
             for blk in net.res_blocks:
                 x32 = blk(x32)
         err32 = float((x32.double() - x64).abs().max())
-        print("f16x3 tower %dx%d: blocks %d max|err| %.3e (fp32 module %.3e) scale %.3e" % (R, R, blocks, err, err32, scale))
+        print("f16x3 tower %dx%d c%d: blocks %d max|err| %.3e (fp32 module %.3e) scale %.3e" % (R, C, ch, blocks, err, err32, scale))
         assert err <= 2e-6 * scale, (blocks, err, scale)
         p, v = ev(planes)
         ep, evv = float((p.double() - p64).abs().max()), float((v.double() - v64).abs().max())
@@ -357,18 +322,50 @@ def test_split_f16_tower_kernel_is_float32_grade(R):
         assert torch.allclose(p.sum(1), torch.ones(G, device="cuda"), atol=1e-5)
 
 
-@pytest.mark.parametrize("R", [8, 6, 12])
-def test_split_f16_evaluator_row_compaction_is_bit_exact(R):
+def test_fc_heads_kernel_is_float32_grade_and_skips_dead_rows():
+    """csrc/yy_fc_heads.hip (policy_fc + value_fc1 as one split-f16 GEMM kernel) against float64 matmuls of the same weights:
+    within 2e-6 of the output scale; rows past the device-side count are neither read (NaN there must not spread) nor written."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    E = pkg.engine
+    for (R, C) in ((8, 8), (6, 6), (12, 12), (5, 7)):
+        torch.manual_seed(3)
+        net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(R, C), 32, 1).cuda().eval()
+        with torch.no_grad():
+            net.policy_fc.bias.normal_(0, 0.1)
+            net.value_fc1.bias.normal_(0, 0.1)
+        ev = pkg.BatchedEvaluator(net, "f16x3")
+        K, A, H = 32 * R * C, R * C, 256
+        G, live = 200, 131
+        feats = torch.rand((G, 2, K), device="cuda") * 3.0
+        feats[feats < 1.2] = 0.0                                            # ReLU outputs: many exact zeros
+        feats[live:] = float("nan")
+        n = torch.tensor([live], dtype=torch.int32, device="cuda")
+        logits = torch.full((G, A), -5.0, device="cuda")
+        hidden = torch.full((G, H), -5.0, device="cuda")
+        E.fc_heads(feats, ev.fc_w, ev.fc_b, ev.fc_jobs, A, H, ev.fc_exps, n, logits, hidden)
+        f64 = feats[:live].double()
+        want_l = f64[:, 0] @ net.policy_fc.weight.double().t() + net.policy_fc.bias.double()
+        want_h = f64[:, 1] @ net.value_fc1.weight.double().t() + net.value_fc1.bias.double()
+        el = float((logits[:live].double() - want_l).abs().max()) / float(want_l.abs().max())
+        eh = float((hidden[:live].double() - want_h).abs().max()) / float(want_h.abs().max())
+        print("fc heads %dx%d: logits err %.2e hidden err %.2e of scale" % (R, C, el, eh))
+        assert el < 2e-6 and eh < 2e-6
+        assert bool((logits[live:] == -5.0).all()) and bool((hidden[live:] == -5.0).all())
+
+
+@pytest.mark.parametrize("R,C,ch", [(8, 8, 128), (6, 6, 128), (12, 12, 128), (5, 7, 96), (10, 10, 64)])
+def test_split_f16_evaluator_row_compaction_is_bit_exact(R, C, ch):
     """evaluator(planes, needs_eval): the flagged rows hold exactly the bits of the full evaluation (a board's output does
     not depend on the workgroup / row it is evaluated in), the other rows are zero; every pattern incl. none and all."""
     import torch
     import yinyang_game_alphazero_amd as pkg
-    game = pkg.YinYangGame(R, R)
-    net = _randomized_net(pkg, game, 2, 3)
+    game = pkg.YinYangGame(R, C)
+    net = _randomized_net(pkg, game, 2, 3, ch)
     ev = pkg.BatchedEvaluator(net, "f16x3")
     rng = np.random.default_rng(9)
     for G in (1, 2, 5, 64, 333):
-        planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
+        planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, C)).astype(np.int8)).cuda())
         p_all, v_all = ev(planes)
         for frac in (0.0, 0.5, 0.94, 1.0):
             flags = torch.from_numpy((rng.random(G) < frac).astype(np.uint8)).cuda()
@@ -381,62 +378,99 @@ def test_split_f16_evaluator_row_compaction_is_bit_exact(R):
             assert float(p[~keep].abs().sum()) == 0.0 and float(v[~keep].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("R", [8, 6, 12])
-def test_split_f16_register_ring_kernel_equals_lds_ring_kernel(R):
-    """csrc/yy_tower_h3r.hip (weight stream in registers) against csrc/yy_tower_h3q.hip (wave-private LDS rings; 8x8: two boards
-    per workgroup above 256 boards, one below): every output element is accumulated in the same order, so the bits are
-    identical -- for the tower activations and for the head features, also through a row gather and across batch sizes."""
+@pytest.mark.parametrize("R,C,ch", [(8, 8, 128), (6, 6, 128), (12, 12, 128), (5, 7, 96), (4, 4, 32)])
+def test_split_f16_every_kernel_form_writes_the_same_bits(R, C, ch):
+    """csrc/yy_tower_g.hip: every (column blocks, boards per workgroup) form accumulates each output element in the same order,
+    so tower activations and head features are bit-identical whichever form evaluates a board -- also through a row gather,
+    across batch sizes, and for every number of boards per workgroup the form admits."""
     import torch
     import yinyang_game_alphazero_amd as pkg
-    game = pkg.YinYangGame(R, R)
-    net = _randomized_net(pkg, game, 10, 5)
+    E = pkg.engine
+    game = pkg.YinYangGame(R, C)
+    net = _randomized_net(pkg, game, 10 if ch == 128 else 3, 5, ch)
     ev = pkg.BatchedEvaluator(net, "f16x3")
     rng = np.random.default_rng(13)
-    G = 37 if R != 8 else 300          # 8x8: > 256 boards -> the two-boards-per-workgroup LDS-ring form
-    planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
-    n_tower = 9 + 36 * (ev.h3_layers - 1)
-    bias_t = ev.h3_b[:ev.h3_layers].contiguous()
-    f_q = pkg.engine.tower_heads_forward_h3(planes, ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)
-    x_q = pkg.engine.tower_forward_h3(planes, ev.h3_w[:n_tower].contiguous(), bias_t, ev.h3_layers, ev.h3_exps)
-    f_r = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps)
-    x_r = pkg.engine.tower_forward_h3r(planes, ev.h3r_w, bias_t, ev.h3_layers, ev.h3_exps)
-    assert torch.equal(f_q, f_r) and torch.equal(x_q, x_r)
+    G = 117
+    planes = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, C)).astype(np.int8)).cuda())
+    ref_f = ref_x = None
+    for nb in E.tower_g_available(ch):
+        tb_max = (16 * nb) // (R * C)
+        for tb in sorted({1, tb_max} - {0}):
+            if tb > tb_max:
+                continue
+            f = E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb, ev.g_hw, ev.g_hb)
+            x = E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb)
+            if ref_f is None:
+                ref_f, ref_x = f, x
+            assert torch.equal(f, ref_f) and torch.equal(x, ref_x), (nb, tb)
+    assert ref_f is not None
     flags = torch.from_numpy((rng.random(G) < 0.6).astype(np.uint8)).cuda()
-    rows, n = pkg.engine.compact_rows(flags)
+    rows, n = E.compact_rows(flags)
     k = int(n)
-    fr = pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n)
-    assert torch.equal(fr[:k], f_q[rows[:k].long()])
-    if R == 8:      # a small batch (one board per workgroup) gives the same bits for the same boards
-        f_small = pkg.engine.tower_heads_forward_h3(planes[:100].contiguous(), ev.h3_w, ev.h3_b, ev.h3_layers, ev.h3_exps)
-        assert torch.equal(f_small, f_q[:100])
+    nb, tb = ev.g_big
+    fr = E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb, ev.g_hw, ev.g_hb, rows, n)
+    assert torch.equal(fr[:k], ref_f[rows[:k].long()])
+    f_small = E.tower_g(planes[:40].contiguous(), ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb, ev.g_hw, ev.g_hb)
+    assert torch.equal(f_small, ref_f[:40])
 
 
 def test_split_f16_form_chosen_on_the_device_writes_the_same_bits():
-    """engine.tower_heads_forward_h3_auto: both 8x8 kernel forms are launched, gated on the device-side live row count (<= 320
-    rows: one board per workgroup, more: two boards per workgroup with the register ring).  For row counts on both sides of the
-    split, at it, zero and the whole batch: the rows written equal the register-ring kernel's bit for bit, rows past the count
-    stay untouched, and the evaluator (which takes this path for 256 < G <= 2048) returns what the dense evaluation returns."""
+    """BatchedEvaluator with compaction on a mid-size batch: both kernel forms of the tower are enqueued, gated on the device-side
+    live row count (<= 320 rows: one 8x8 board per workgroup, more: two).  For row counts on both sides of the split, at it,
+    zero and the whole batch: the evaluator returns what the dense evaluation returns, bit for bit, and the gated launches
+    write exactly the rows below the count."""
     import torch
     import yinyang_game_alphazero_amd as pkg
     E = pkg.engine
     torch.manual_seed(0)
     net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
     ev = pkg.BatchedEvaluator(net, "f16x3")
+    assert ev.g_small == (4, 1) and ev.g_big == (8, 2) and ev.g_split == 320
     G = 1024
     rng = np.random.default_rng(4)
     planes = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
     dense_p, dense_v = ev(planes)
+    dense_f = E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 8, 2, ev.g_hw, ev.g_hb)
     for n_live in (0, 1, 7, 319, 320, 321, 600, 1024):
         flags = torch.zeros(G, dtype=torch.uint8, device="cuda")
         flags[torch.from_numpy(rng.choice(G, n_live, replace=False)).cuda()] = 1
         rows, n = E.compact_rows(flags)
         assert int(n) == n_live
-        want = torch.full((G, 2, 2048), -7.0, device="cuda")
-        got = want.clone()
-        E.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n, want)
-        E.tower_heads_forward_h3_auto(planes, ev.h3_w, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps, rows, n, 320, got)
-        assert torch.equal(want, got), n_live
+        got = torch.full((G, 2, 2048), -7.0, device="cuda")
+        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 4, 1, ev.g_hw, ev.g_hb, rows, n, got, (-1, 320))
+        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 8, 2, ev.g_hw, ev.g_hb, rows, n, got, (320, 0x7FFFFFFF))
+        assert torch.equal(got[:n_live], dense_f[rows[:n_live].long()]), n_live
         assert n_live == G or bool((got[n_live:] == -7.0).all())
         p, v = ev(planes, needs_eval=flags)
         live = flags.bool()
         assert torch.equal(p[live], dense_p[live]) and torch.equal(v[live], dense_v[live]), n_live
+
+
+@pytest.mark.parametrize("R", [8, 6, 12])
+def test_evaluator_rows_do_not_depend_on_the_batch(R):
+    """The property the engine's evaluation reuse rests on (BatchedEvaluator.row_independent; YY_FLAG_REUSE_*, the opening book):
+    a row's (policy, value) is a function of that row's planes alone, bit for bit.  The same 512 random positions of the 128 x 10
+    network evaluated in batches of M = 1 ... 8192 rows (every drain tier of the engine, the book's batch, ragged sizes; dense
+    and through the row compaction, static buffers or fresh ones): identical bits per row.  True by construction -- the tower
+    and our own FC-head kernel accumulate every output in a fixed order; no library GEMM on the path."""
+    import torch
+    import yinyang_game_alphazero_amd as pkg
+    E = pkg.engine
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(R, R)).cuda().eval()
+    ev = pkg.BatchedEvaluator(net)
+    assert ev.mode == "f16x3" and ev.row_independent
+    rng = np.random.default_rng(21)
+    B = 512
+    base = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(B, R, R)).astype(np.int8)).cuda())
+    p_ref, v_ref = (t.clone() for t in ev(base))
+    assert bool(torch.isfinite(p_ref).all()) and bool(torch.isfinite(v_ref).all())
+    for M in (1, 96, 256, 320, 321, 1024, 3072, 3928, 4096, 8192):
+        idx = torch.from_numpy(rng.integers(0, B, size=M)).cuda() if M > 1 else torch.tensor([77], device="cuda")
+        planes = base[idx].contiguous()
+        p, v = ev(planes)
+        assert torch.equal(p, p_ref[idx]) and torch.equal(v, v_ref[idx]), ("dense", M)
+        flags = torch.from_numpy((rng.random(M) < 0.3).astype(np.uint8)).cuda()
+        p, v = ev(planes, needs_eval=flags, static=True)
+        live = flags.bool()
+        assert torch.equal(p[live], p_ref[idx][live]) and torch.equal(v[live], v_ref[idx][live]), ("compacted", M)

@@ -59,7 +59,9 @@ def main():
     ev = pkg.BatchedEvaluator(net, "f16x3")
     rng = np.random.default_rng(0)
     planes = pkg.engine.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, R, R)).astype(np.int8)).cuda())
-    launch = lambda: pkg.engine.tower_heads_forward_h3r(planes, ev.h3r_w, ev.h3r_hw, ev.h3_b, ev.h3_layers, ev.h3_exps)
+    nb, tb = ev.g_big
+    feats = torch.empty((G, 2, 32 * R * R), dtype=torch.float32, device="cuda")
+    launch = lambda: pkg.engine.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, nb, tb, ev.g_hw, ev.g_hb, out=feats)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()

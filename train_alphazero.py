@@ -40,9 +40,9 @@ def parse_args(argv=None):
     p.add_argument("--concurrent-games", type=int, default=4096)
     p.add_argument("--board-semantics", choices=["copied", "aliased"], default="copied")
     p.add_argument("--reference-quirks", action="store_true", help="reproduce Q4/Q5 of the reference's play_game")
-    p.add_argument("--nn", choices=["auto", "f16x3", "bf16", "fp32", "fp32t", "bf16x3"], default="auto",
+    p.add_argument("--nn", choices=["auto", "f16x3", "bf16", "fp32", "fp32t"], default="auto",
                    help="evaluator: auto = float32-accurate (f16x3 split-f16 tower where the kernels cover the shape, else the fp32 module; the "
-                        "reference evaluates in float32); bf16 = reduced-precision fast tower; fp32t exact-f32 tower; bf16x3 split-bf16")
+                        "reference evaluates in float32); bf16 = reduced-precision fast tower; fp32t exact-f32 tower (8x8, 128 channels)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--evaluation-reuse", choices=["auto", "off"], default="auto",
                    help="auto: the network is asked once per position of a game (pass values + per-game evaluation cache; "

@@ -35,8 +35,8 @@ class MctsConfig(C.Structure):
 
 def build(force=False, verbose=False):
     """Compile csrc/yy_engine.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "yy_engine.hip"), os.path.join(CSRC, "yy_tower.hip"), os.path.join(CSRC, "yy_towerq.hip"), os.path.join(CSRC, "yy_tower_f32.hip"), os.path.join(CSRC, "yy_tower_x3.hip"), os.path.join(CSRC, "yy_tower_h3.hip"), os.path.join(CSRC, "yy_tower_h3q.hip"), os.path.join(CSRC, "yy_tower_h3r.hip"), os.path.join(CSRC, "yy_selfplay.hip"),
-            os.path.join(CSRC, "yy_bitboard.h"), HEADER]
+    srcs = [os.path.join(CSRC, f) for f in ("yy_engine.hip", "yy_tower.hip", "yy_towerq.hip", "yy_tower_f32.hip", "yy_tower_h3r.hip",
+                                            "yy_tower_g.hip", "yy_fc_heads.hip", "yy_selfplay.hip", "yy_bitboard.h")] + [HEADER]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in srcs):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -86,15 +86,14 @@ _SIGS = {
     "yy_nn_tower_heads_bf16": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_head_finish_bf16": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     "yy_nn_tower_f32": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "yy_nn_tower_bf16x3": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "yy_nn_tower_f16x3": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "yy_nn_tower_heads_f16x3": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_head_finish_f32": [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "yy_compact_rows": [_vp, C.c_int, _vp, _vp, _vp],
-    "yy_nn_tower_heads_f16x3_auto": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, C.c_int, _vp],
     "yy_nn_tower_f16x3_regs": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, _vp],
+    "yy_nn_tower_g_forms": [C.c_int, C.POINTER(C.c_int)],
+    "yy_nn_tower_g": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "yy_nn_fc_heads_f16x3": [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "yy_selfplay_root_noise": [C.c_uint64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp, _vp],
     "yy_selfplay_sample_actions": [C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "yy_version": [],

@@ -1,5 +1,5 @@
-// yy_tower_h3r.hip -- the split-f16 (float32-accurate) tower of yy_tower_h3.hip / yy_tower_h3q.hip with the weight stream
-// kept in REGISTERS: wave w = output channels [32w, 32w+32) x all (board, cell) columns of the workgroup.  Template
+// yy_tower_h3r.hip -- the round-2 split-f16 (float32-accurate) tower on v_mfma_f32_32x32x16_f16 with the weight stream kept in
+// REGISTERS, now the A/B partner of the general kernel (yy_tower_g.hip; evaluator mode "f16x3r"): wave w = output channels [32w, 32w+32) x all (board, cell) columns of the workgroup.  Template
 // <R, TB, D, NV>: TB boards of R x R cells per workgroup, a ring of D weight chunks per wave, NV of them in VGPRs:
 //   <8, 2, 9, 4>  8x8, two boards = four 32-column tiles: the headline evaluator kernel (BASELINE config 2);
 //   <6, 4, 3, 2>  6x6, four boards, and <12, 1, 3, 2> 12x12, one board: 144 columns = five tiles (the last half padding);
@@ -15,10 +15,9 @@
 // form with wave-private LDS rings) and 3.72 ms (board x cout-half form, shared LDS ring) in the same process.
 // LDS now holds only the activations ({hi, lo} x (columns + a zero row) x 272 B), the bias table and (8x8) the f32 residual.
 //
-// Numerics (yy_tower_h3.hip): x = hi + lo with hi = f16(x), lo = f16(x - hi); weights are stored times 2^kw and activations (and
+// Numerics (as yy_tower_g.hip): x = hi + lo with hi = f16(x), lo = f16(x - hi); weights are stored times 2^kw and activations (and
 // the bias table) live times 2^ka so that the lo parts stay in float16's normal range; per tile one f32 accumulator takes
-// w_hi*x_hi and a second one w_lo*x_hi + w_hi*x_lo; the epilogue is fma(acc1 + acc2, 2^-kw, bias).  Output bits equal
-// yy_tower_h3q.hip's (tested).  Weight layout ("wave-major",
+// w_hi*x_hi and a second one w_lo*x_hi + w_hi*x_lo; the epilogue is fma(acc1 + acc2, 2^-kw, bias).  Weight layout ("wave-major",
 // network.pack_tower_h3r): chunk = one tap x 32 input channels = [nt 4][ks 2][part 2][h 2][c 32][j 8] f16 (4 KB per wave,
 // contiguous), cin = quarter*32 + ks*16 + h*8 + j, cout = nt*32 + c; stem: one chunk per tap (ks 0 only carries data), every
 // other layer 36 (tap-major, then quarter); heads: [head 2][ks 8][part 2][h 2][c 32][j 8] (cin = ks*16 + h*8 + j).
@@ -403,12 +402,4 @@ extern "C" int yy_nn_tower_f16x3_regs(const float *planes, const void *weights, 
     if (R == 8) return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     if (R == 6) return launch_hr<6, 4, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
     return launch_hr<12, 1, 3, 2>(planes, weights, head_w, bias, out, out_heads, rows, n_rows, G, n_layers, sc, s);
-}
-
-// 8x8 form with a device-side gate on the live row count (yy_tower_h3.hip: yy_nn_tower_heads_f16x3_auto)
-extern "C" int yy_tower_h3r_launch8_gated(const float *planes, const void *weights, const void *head_w, const float *bias,
-                                          float *out_heads, const int *rows, const int *n_rows, int G, int n_layers,
-                                          const float *sc, int gate_lo, int gate_hi, yy_stream_t s) {
-    const float scl[4] = {sc[0], sc[1], sc[2], sc[3]};
-    return launch_hr<8, 2, 9, 4>(planes, weights, head_w, bias, nullptr, out_heads, rows, n_rows, G, n_layers, scl, s, gate_lo, gate_hi);
 }

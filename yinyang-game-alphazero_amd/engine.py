@@ -163,57 +163,10 @@ def tower_forward_f32(planes, weights, bias, n_layers):
     return out.permute(0, 3, 1, 2)
 
 
-def tower_forward_x3(planes, weights, bias, n_layers):
-    """Stem + residual tower at float32-grade accuracy on the bf16 MFMA (split-bf16, csrc/yy_tower_x3.hip).
-    planes f32 [G,5,8,8] -> f32 activations as a channels-last tensor [G,128,8,8]."""
-    G = planes.shape[0]
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
-    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "split-bf16 tower weights")
-    _need(bias, torch.float32, (n_layers, 128), "tower bias")
-    out = torch.empty((G, 8, 8, 128), dtype=torch.float32, device=planes.device)
-    with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_bf16x3(_p(planes), _p(weights), _p(bias), _p(out), G, 8, 8, 128, n_layers, _stream()))
-    return out.permute(0, 3, 1, 2)
-
-
-def tower_forward_h3(planes, weights, bias, n_layers, exps):
-    """Stem + residual tower at float32 accuracy on the f16 MFMA (split-f16, csrc/yy_tower_h3.hip / yy_tower_h3q.hip).
-    planes f32 [G,5,R,R] (R = 6, 8, 12) -> f32 activations as a channels-last tensor [G,128,R,R]."""
-    G, _, R, Cc = planes.shape
-    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
-    _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "split-f16 tower weights")
-    _need(bias, torch.float32, (n_layers, 128), "tower bias")
-    out = torch.empty((G, R, Cc, 128), dtype=torch.float32, device=planes.device)
-    with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_f16x3(_p(planes), _p(weights), _p(bias), _p(out), G, R, Cc, 128, n_layers, int(exps[0]), int(exps[2]),
-                                      _stream()))
-    return out.permute(0, 3, 1, 2)
-
-
-def tower_heads_forward_h3(planes, weights, bias, n_layers, exps, rows=None, n_rows=None, out=None):
-    """Split-f16 tower + fused 1x1 head convolutions: planes f32 [G,5,R,R] -> f32 [G,2,32*R*R] = (policy features, value
-    features) in the reference's flatten order.  rows int32 [G] / n_rows int32 [1] (device): evaluate planes[rows[i]] for
-    i < n_rows into output row i (the other output rows are left untouched).  exps = (kw, kh, ka): the power-of-two scales of
-    the packed weights / head weights / activations (network.pack_tower_h3)."""
-    G, _, R, Cc = planes.shape
-    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
-    _need(weights, torch.int16, (9 + 36 * (n_layers - 1) + 2, 8192), "split-f16 tower+heads weights")
-    _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
-    if rows is not None:
-        _need(rows, torch.int32, (G,), "rows")
-        _need(n_rows, torch.int32, (1,), "n_rows")
-    if out is None:
-        out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
-    _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
-    with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_heads_f16x3(_p(planes), _p(weights), _p(bias), _p(out), _p(rows), _p(n_rows), G, R, Cc, 128,
-                                            n_layers, int(exps[0]), int(exps[1]), int(exps[2]), _stream()))
-    return out
-
-
 def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, exps, rows=None, n_rows=None, out=None):
-    """tower_heads_forward_h3 with the weight stream in registers (csrc/yy_tower_h3r.hip; boards 6x6 / 8x8 / 12x12); weights in
-    the wave-major order of network.pack_tower_h3r / pack_heads_h3r.  Same bits."""
+    """The 32x32x16 split-f16 tower of round 2 (csrc/yy_tower_h3r.hip; boards 6x6 / 8x8 / 12x12, 128 channels): the A/B partner
+    of tower_g.  planes f32 [G,5,R,R] -> f32 [G,2,32*R*R] head features; weights in the wave-major order of
+    network.pack_tower_h3r / pack_heads_h3r; rows / n_rows as for tower_g."""
     G, _, R, Cc = planes.shape
     _need(planes, torch.float32, (G, 5, R, Cc), "planes")
     _need(weights, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
@@ -231,28 +184,6 @@ def tower_heads_forward_h3r(planes, weights, head_w, bias, n_layers, exps, rows=
     return out
 
 
-def tower_heads_forward_h3_auto(planes, weights_lds, weights_regs, head_w_regs, bias, n_layers, exps, rows, n_rows, split=320,
-                                out=None):
-    """8x8: tower_heads_forward_h3 / _h3r on the compacted rows with the kernel form chosen on the device from n_rows (at most
-    `split` live rows: one board per workgroup; more: two boards per workgroup, register ring).  Same bits either way."""
-    G, _, R, Cc = planes.shape
-    _need(planes, torch.float32, (G, 5, 8, 8), "planes")
-    _need(weights_lds, torch.int16, (9 + 36 * (n_layers - 1) + 2, 8192), "split-f16 tower+heads weights")
-    _need(weights_regs, torch.int16, (9 + 36 * (n_layers - 1), 8192), "wave-major split-f16 tower weights")
-    _need(head_w_regs, torch.int16, (2, 8192), "wave-major split-f16 head weights")
-    _need(bias, torch.float32, (n_layers + 1, 128), "tower+heads bias")
-    _need(rows, torch.int32, (G,), "rows")
-    _need(n_rows, torch.int32, (1,), "n_rows")
-    if out is None:
-        out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
-    _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
-    with torch.cuda.device(planes.device):
-        check(lib().yy_nn_tower_heads_f16x3_auto(_p(planes), _p(weights_lds), _p(weights_regs), _p(head_w_regs), _p(bias), _p(out),
-                                                 _p(rows), _p(n_rows), G, R, Cc, 128, n_layers, int(exps[0]), int(exps[1]),
-                                                 int(exps[2]), int(split), _stream()))
-    return out
-
-
 def tower_forward_h3r(planes, weights, bias, n_layers, exps):
     """Tower activations f32 [G,128,R,R] (channels-last memory) from the register-ring kernel (tests)."""
     G, _, R, Cc = planes.shape
@@ -264,6 +195,68 @@ def tower_forward_h3r(planes, weights, bias, n_layers, exps):
         check(lib().yy_nn_tower_f16x3_regs(_p(planes), _p(weights), None, _p(bias), _p(out), None, None, None, G, R, Cc, 128, n_layers,
                                            int(exps[0]), 0, int(exps[2]), _stream()))
     return out.permute(0, 3, 1, 2)
+
+
+def tower_g_available(channels):
+    """Column-block counts the general split-f16 tower kernel is instantiated for at this channel count."""
+    buf = (ct.c_int * 8)()
+    n = lib().yy_nn_tower_g_forms(int(channels), buf)
+    return [int(buf[i]) for i in range(n)]
+
+
+def tower_g(planes, weights, bias, n_layers, exps, nb, boards, head_w=None, head_bias=None, rows=None, n_rows=None, out=None,
+            gate=(-1, 0x7FFFFFFF)):
+    """General split-f16 tower (csrc/yy_tower_g.hip): planes f32 [G,5,R,C] (R*C <= 144) with the weights of network.pack_tower_g.
+    With head_w / head_bias (pack_heads_g): -> f32 [G,2,32*R*C] = (policy features, value features) in the reference's flatten
+    order; without: -> the tower activations f32 [G,CH,R,C] (channels-last memory).  nb column blocks of 16 and `boards` boards
+    per workgroup (network.tower_g_forms).  rows int32 [G] / n_rows int32 [1] (device): evaluate planes[rows[i]] for i < n_rows
+    into dense row i; gate = (lo, hi): the launch only runs when lo < live rows <= hi."""
+    G, _, R, Cc = planes.shape
+    _need(planes, torch.float32, (G, 5, R, Cc), "planes")
+    ch = bias.shape[1]
+    nw = ch // 32
+    _need(weights, torch.int16, (9 + 9 * nw * (n_layers - 1), ch * 64), "split-f16 tower weights (pack_tower_g)")
+    _need(bias, torch.float32, (n_layers, ch), "tower bias")
+    if rows is not None:
+        _need(rows, torch.int32, (G,), "rows")
+        _need(n_rows, torch.int32, (1,), "n_rows")
+    heads = head_w is not None
+    if heads:
+        _need(head_w, torch.int16, (4 * nw * 2 * 512,), "split-f16 head weights (pack_heads_g)")
+        _need(head_bias, torch.float32, (64,), "head bias")
+        if out is None:
+            out = torch.empty((G, 2, 32 * R * Cc), dtype=torch.float32, device=planes.device)
+        _need(out, torch.float32, (G, 2, 32 * R * Cc), "out")
+    else:
+        out = torch.empty((G, R, Cc, ch), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib().yy_nn_tower_g(_p(planes), _p(weights), _p(head_w), _p(bias), _p(head_bias), None if heads else _p(out),
+                                  _p(out) if heads else None, _p(rows), _p(n_rows), G, R, Cc, ch, n_layers, int(exps[0]), int(exps[1]),
+                                  int(exps[2]), int(nb), int(boards), int(gate[0]), int(gate[1]), _stream()))
+    return out if heads else out.permute(0, 3, 1, 2)
+
+
+def fc_heads(feats, wpk, bias, jobs, A, H, exps, n_rows=None, logits=None, hidden=None):
+    """policy_fc and value_fc1 on the dense feature rows (csrc/yy_fc_heads.hip): feats f32 [G,2,K] -> (logits f32 [G,A], hidden
+    f32 [G,H], bias added); weights / bias / jobs from network.pack_fc_heads, exps = (kw, ka).  n_rows int32 [1] (device): rows
+    past it are neither read nor written.  A row's results do not depend on G, n_rows or its position in the batch."""
+    G, two, K = feats.shape
+    _need(feats, torch.float32, (G, 2, K), "feats")
+    _need(jobs, torch.int32, (jobs.shape[0], 4), "jobs")
+    ksteps = ((K + 127) // 128) * 4
+    _need(wpk, torch.int16, (jobs.shape[0] * ksteps * 4096,), "fc head weights (pack_fc_heads)")
+    _need(bias, torch.float32, (A + H,), "fc head bias")
+    if n_rows is not None:
+        _need(n_rows, torch.int32, (1,), "n_rows")
+    if logits is None:
+        logits = torch.empty((G, A), dtype=torch.float32, device=feats.device)
+        hidden = torch.empty((G, H), dtype=torch.float32, device=feats.device)
+    _need(logits, torch.float32, (G, A), "logits")
+    _need(hidden, torch.float32, (G, H), "hidden")
+    with torch.cuda.device(feats.device):
+        check(lib().yy_nn_fc_heads_f16x3(_p(feats), _p(wpk), _p(bias), _p(jobs), jobs.shape[0], _p(logits), _p(hidden), _p(n_rows), G, K,
+                                         A, H, int(exps[0]), int(exps[1]), _stream()))
+    return logits, hidden
 
 
 def head_finish_f32(logits, hidden, w2, b2, rows=None, n_rows=None, policy=None, value=None):

@@ -16,10 +16,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the split-f16 tower kernels cover (csrc/yy_tower_h3.hip)
-H3R_MIN_ROWS = 256         # above this many rows the 8x8 split-f16 evaluator uses the register-ring kernel (yy_tower_h3r.hip)
-H3_AUTO_MAX_ROWS = 2048          # 8x8 batches up to this size launch both f16x3 forms, gated on the live row count (engine.tower_heads_forward_h3_auto)
-H3_AUTO_SPLIT = 320              # live rows: <= one board per workgroup (LDS ring), > two boards per workgroup (register ring)
+H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the 32x32x16 split-f16 kernels cover (csrc/yy_tower_h3r.hip: A/B partner of the general kernel)
+G_MAX_CELLS = 144                # the general split-f16 tower (csrc/yy_tower_g.hip): any R x C board up to this many cells
+G_CHANNELS = (32, 64, 96, 128)   # ... and these widths
+G_SPLIT_WG = 320                 # live rows <= this many workgroups of the small form: the small form runs (most CUs at work), else the large one
+G_AUTO_MAX_WG = 2048             # batches up to this many small-form workgroups enqueue both forms, gated on the device-side row count
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
 INPUT_PLANES = 5
@@ -180,35 +181,7 @@ def pack_tower_f32(net):
     return torch.stack(chunks).contiguous(), torch.stack(biases).contiguous()
 
 
-def pack_tower_x3(net):
-    """Split-bf16 packing for csrc/yy_tower_x3.hip: every folded float32 weight w becomes hi = bf16(w), lo = bf16(w - hi);
-    chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] bf16 with cout = nt*32 + c and
-    cin = quarter*32 + ks*16 + h*8 + j (part 0 = hi, 1 = lo); the stem has one chunk per tap (5 planes padded to 16
-    channels, ks = 0 only), every other layer 36 (tap-major, then quarter).  Returns int16 [n_chunks, 8192], float32 bias."""
-    convs = [(net.conv1, net.bn1)]
-    for blk in net.res_blocks:
-        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
-    chunks, biases = [], []
-    for li, (conv, bn) in enumerate(convs):
-        w, b = fold_batchnorm(conv, bn)
-        w = w.float().cpu()
-        wp = torch.zeros((128, 128, 3, 3))
-        wp[:, :w.shape[1]] = w
-        hi = wp.to(torch.bfloat16)
-        lo = (wp - hi.float()).to(torch.bfloat16)
-        for tap in range(9):
-            parts = []
-            for t in (hi, lo):
-                t = t[:, :, tap // 3, tap % 3].reshape(4, 32, 4, 2, 2, 8)         # nt, c, quarter, ks, h, j
-                parts.append(t.permute(2, 3, 0, 4, 1, 5))                          # quarter, ks, nt, h, c, j
-            both = torch.stack(parts, dim=2).contiguous()                          # quarter, ks, part, nt, h, c, j
-            for quarter in range(1 if li == 0 else 4):
-                chunks.append(both[quarter].reshape(-1))
-        biases.append(b.float().cpu())
-    return torch.stack(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous()
-
-
-ACT_EXP = 3          # split-f16 tower: activations (and the tower's bias rows) live times 2^ACT_EXP (csrc/yy_tower_h3.hip)
+ACT_EXP = 3          # split-f16 tower: activations (and the tower's bias rows) live times 2^ACT_EXP (csrc/yy_tower_g.hip)
 
 
 def _pow2_exponent(t, target=14):
@@ -220,7 +193,7 @@ def _pow2_exponent(t, target=14):
 
 
 def split_f16(t):
-    """x -> (hi, lo) float16 with x == hi + lo to 22 significant bits (csrc/yy_tower_h3.hip): hi = f16(x), lo = f16(x - hi)."""
+    """x -> (hi, lo) float16 with x == hi + lo to 22 significant bits (csrc/yy_tower_g.hip): hi = f16(x), lo = f16(x - hi)."""
     t = t.float()
     hi = t.to(torch.float16)
     if not bool(torch.isfinite(hi).all()):
@@ -230,7 +203,7 @@ def split_f16(t):
 
 
 def pack_tower_h3(net):
-    """Split-f16 packing for csrc/yy_tower_h3q.hip (evaluator mode "f16x3"): every folded float32 weight w, times 2^kw, becomes
+    """Split-f16 packing for the 32x32x16 kernel (csrc/yy_tower_h3r.hip, evaluator mode "f16x3r"; re-ordered by pack_tower_h3r): every folded float32 weight w, times 2^kw, becomes
     hi = f16(w'), lo = f16(w' - hi); chunk = one tap x 32 input channels = [ks 2][part 2][nt 4][h 2][c 32][j 8] f16 with
     cout = nt*32 + c and cin = quarter*32 + ks*16 + h*8 + j (part 0 = hi, 1 = lo); the stem has one chunk per tap (5 planes
     padded to 16 channels, ks = 0 only), every other layer 36 (tap-major, then quarter).
@@ -288,6 +261,102 @@ def pack_heads_h3r(net):
     return hw.view(2, 4, 2, 2, 512).permute(3, 0, 1, 2, 4).contiguous().view(2, 8192), hb, kh
 
 
+def tower_convs(net):
+    convs = [(net.conv1, net.bn1)]
+    for blk in net.res_blocks:
+        convs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+    return convs
+
+
+def pack_tower_g(net):
+    """Split-f16 packing for csrc/yy_tower_g.hip (v_mfma_f32_16x16x32_f16; any board, 32/64/96/128 channels): every folded
+    float32 weight w, times 2^kw, becomes hi = f16(w'), lo = f16(w' - hi).  A chunk is one tap x 32 input channels for all
+    output channels = [wave CH/32][M block 2][part 2][lane 64][j 8] f16 with cout = wave*32 + mblock*16 + lane%16 and
+    cin = kq*32 + (lane//16)*8 + j (part 0 = hi, 1 = lo): the A operand of the MFMA in register order, 4 KB per wave.
+    Chunk order [layer][kq][tap]; the stem has kq = 0 only (5 planes zero-padded to 32 channels).
+    Returns (int16 [n_chunks, CH*64] f16 bits, float32 bias [n_layers, CH] times 2^ACT_EXP, kw)."""
+    ch = net.conv1.out_channels
+    if ch % 32 or not 32 <= ch <= 128:
+        raise ValueError("split-f16 tower: channels must be 32, 64, 96 or 128")
+    nw = ch // 32
+    folded = [fold_batchnorm(conv, bn) for conv, bn in tower_convs(net)]
+    kw = _pow2_exponent(torch.cat([w.float().reshape(-1) for w, _ in folded]))
+    chunks, biases = [], []
+    for li, (w, b) in enumerate(folded):
+        w = w.float().cpu()
+        cin = w.shape[1]
+        kq_n = 1 if li == 0 else nw
+        wp = torch.zeros((ch, 32 * kq_n, 3, 3))
+        wp[:, :cin] = w
+        hi, lo = split_f16(torch.ldexp(wp, torch.tensor(kw)))
+        both = torch.stack([hi, lo])                                     # part, cout, cin, ky, kx
+        both = both.reshape(2, nw, 2, 16, kq_n, 4, 8, 9)                  # part, wave, mb, m, kq, kg, j, tap
+        both = both.permute(4, 7, 1, 2, 0, 5, 3, 6).contiguous()          # kq, tap, wave, mb, part, kg, m, j
+        chunks.append(both.reshape(kq_n * 9, -1))
+        biases.append(torch.ldexp(b.float().cpu(), torch.tensor(ACT_EXP)))
+    return torch.cat(chunks).view(torch.int16).contiguous(), torch.stack(biases).contiguous(), kw
+
+
+def pack_heads_g(net):
+    """The two 1x1 head convolutions for csrc/yy_tower_g.hip: [unit 4 = head*2 + M block][kq CH/32][part 2][lane 64][j 8] f16 of the
+    folded weights times 2^kh (channel of the head = mblock*16 + lane%16, cin = kq*32 + (lane//16)*8 + j) and the UNSCALED bias
+    [policy 32 | value 32].  Returns (int16 [4*CH/32*2*512], float32 [64], kh)."""
+    wp, bp = fold_batchnorm(net.policy_conv, net.policy_bn)      # [32,CH,1,1]
+    wv, bv = fold_batchnorm(net.value_conv, net.value_bn)
+    if wp.shape[0] != HEAD_CHANNELS or wv.shape[0] != HEAD_CHANNELS:
+        raise ValueError("split-f16 tower: the head convolutions must have 32 channels")
+    w = torch.cat([wp, wv]).float().cpu().reshape(2 * HEAD_CHANNELS, -1)
+    nw = w.shape[1] // 32
+    kh = _pow2_exponent(w)
+    hi, lo = split_f16(torch.ldexp(w, torch.tensor(kh)))
+    both = torch.stack([hi, lo]).reshape(2, 2, 2, 16, nw, 4, 8)         # part, head, mb, m, kq, kg, j
+    both = both.permute(1, 2, 4, 0, 5, 3, 6).contiguous()               # head, mb, kq, part, kg, m, j
+    return both.reshape(-1).view(torch.int16).contiguous(), torch.cat([bp, bv]).float().cpu().contiguous(), kh
+
+
+def pack_fc_heads(net):
+    """policy_fc and value_fc1 for csrc/yy_fc_heads.hip: the outputs of each head are cut into slices of at most 64 (a job);
+    a slice's weights, times 2^kw and split into hi / lo float16, are stored [k-step ceil(K/128)*4][wave 4][part 2][lane 64][j 8]
+    with output = first + wave*16 + lane%16 and k = kstep*32 + (lane//16)*8 + j (zero beyond the slice / beyond K).
+    Returns (int16 weights, float32 bias [A + H], int32 jobs [n_jobs, 4] = (head, first output, outputs, first 8 KB block), kw)."""
+    mats = [net.policy_fc.weight.detach().float().cpu(), net.value_fc1.weight.detach().float().cpu()]
+    K = mats[0].shape[1]
+    ksteps = ((K + 127) // 128) * 4
+    kw = _pow2_exponent(torch.cat([m.reshape(-1) for m in mats]))
+    blocks, jobs = [], []
+    for head, w in enumerate(mats):
+        for first in range(0, w.shape[0], 64):
+            n = min(64, w.shape[0] - first)
+            wp = torch.zeros((64, ksteps * 32))
+            wp[:n, :K] = w[first:first + n]
+            hi, lo = split_f16(torch.ldexp(wp, torch.tensor(kw)))
+            both = torch.stack([hi, lo]).reshape(2, 4, 16, ksteps, 4, 8)            # part, wave, m, kstep, kg, j
+            blocks.append(both.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1))   # kstep, wave, part, kg, m, j
+            jobs.append((head, first, n, len(jobs) * ksteps))
+    bias = torch.cat([net.policy_fc.bias.detach().float().cpu(), net.value_fc1.bias.detach().float().cpu()]).contiguous()
+    return torch.cat(blocks).view(torch.int16).contiguous(), bias, torch.tensor(jobs, dtype=torch.int32), kw
+
+
+def tower_g_forms(cells, channels):
+    """(column blocks, boards per workgroup) choices of the general split-f16 tower for a board of `cells` cells:
+    (large-batch form, small-batch form).  A form covers 16 * nb (board, cell) columns; boards * cells of them are real."""
+    from . import engine
+    forms = engine.tower_g_available(channels)
+    best = small = None
+    for nb in forms:
+        tb = (16 * nb) // cells
+        if tb < 1:
+            continue
+        eff = tb * cells / (16.0 * nb)
+        if best is None or (eff, nb) > (best[2], best[0]):      # least padding; ties: the larger tile (more weight reuse)
+            best = (nb, tb, eff)
+        if small is None or (tb, nb) < (small[1], small[0]):   # fewest boards per workgroup: most workgroups for few rows
+            small = (nb, tb, eff)
+    if best is None:
+        raise ValueError("split-f16 tower: no kernel form for %d cells" % cells)
+    return best[:2], small[:2]
+
+
 def pack_heads(net):
     """The two 1x1 head convolutions (policy_conv/policy_bn, value_conv/value_bn) as one extra chunk
     [ks 8][nt 2][h 2][c 32][j 8] (nt 0 = policy channels, nt 1 = value channels, cin = ks*16 + h*8 + j)
@@ -303,26 +372,33 @@ def pack_heads(net):
 
 def reference_precision_mode(net):
     """The fastest evaluator mode that is float32-ACCURATE for this network (the reference evaluates in float32,
-    neural_network.py:125-154): "f16x3" where the split-f16 tower kernels cover the shape, else "fp32" (the module itself)."""
-    ok = (tuple(net.board_size) in H3_BOARDS and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10
-          and net.policy_conv.out_channels == 32)
-    return "f16x3" if ok else "fp32"
+    neural_network.py:125-154): "f16x3" where the split-f16 kernels cover the shape (f16x3_covers), else "fp32" (the module itself)."""
+    return "f16x3" if f16x3_covers(net) else "fp32"
+
+
+def f16x3_covers(net):
+    """True where the split-f16 kernels (csrc/yy_tower_g.hip + yy_fc_heads.hip) cover the network: any board of at most 144 cells,
+    32 / 64 / 96 / 128 channels, at most 10 residual blocks, 32-channel head convolutions."""
+    R, C = net.board_size
+    return (R * C <= G_MAX_CELLS and net.conv1.out_channels in G_CHANNELS and len(net.res_blocks) <= 10
+            and net.policy_conv.out_channels == HEAD_CHANNELS and net.value_conv.out_channels == HEAD_CHANNELS)
 
 
 class BatchedEvaluator:
     """Callable evaluator for BatchedMCTS.search: planes f32 [G,5,R,C] -> (policy f32 [G,A], value f32 [G]).
 
     mode "auto" (default): `reference_precision_mode(net)` -- "f16x3" where the kernels cover the shape, else "fp32".
-    mode "f16x3": float32 ACCURACY on the f16 matrix cores (csrc/yy_tower_h3.hip, yy_tower_h3r.hip, yy_tower_h3q.hip): activations
-    and weights as hi + lo float16 pairs (22 significant bits), three MFMAs per product term, f32 accumulation / bias / residual,
-    1x1 head convs fused, FC heads as float32 GEMMs + one finish kernel.  Searches driven by it return the reference's visit
-    counts (tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi); supports row compaction.
+    mode "f16x3": float32 ACCURACY on the f16 matrix cores (csrc/yy_tower_g.hip + yy_fc_heads.hip): activations and weights as
+    hi + lo float16 pairs (22 significant bits), three MFMAs per product term, f32 accumulation / bias / residual, 1x1 head
+    convs fused into the tower kernel, FC heads as one split-f16 GEMM kernel of our own + one finish kernel.  Any board of at
+    most 144 cells, 32 / 64 / 96 / 128 channels.  Searches driven by it return the reference's visit counts
+    (tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi); supports row compaction; a row's results do not
+    depend on the batch (row_independent).
+    mode "f16x3r": the same evaluator with the round-2 32x32x16 tower kernel (csrc/yy_tower_h3r.hip; 6x6 / 8x8 / 12x12, 128
+    channels) in place of the general one: the A/B partner for timing.
     mode "fp32": the module as is (same arithmetic as predict()).
     mode "fp32t": the same float32 weights, but the stem + residual tower run in the hand-written exact-f32 MFMA kernel
     (csrc/yy_tower_f32.hip; 8x8 boards, 128 channels); heads by torch in float32.  Differs from "fp32" only by summation order.
-    mode "bf16x3": float32-grade accuracy on the bf16 matrix cores (csrc/yy_tower_x3.hip): activations and weights as
-    (hi, lo) bf16 pairs, three MFMAs per product term, f32 accumulation / bias / residual; heads by torch in float32.  Agrees
-    with "fp32" to ~1e-5 on the policy at about a third of the "fp32t" cost.
     mode "bf16"/"fp16": inference-only fast path -- eval-mode BatchNorm folded into the convs,
     channels-last activations, reduced-precision MFMA convolutions (MIOpen implicit GEMM), softmax/tanh
     in fp32.  In bf16 mode with `fused_epilogue` (default) every convolution is issued WITHOUT bias and
@@ -341,39 +417,51 @@ class BatchedEvaluator:
         # blocks (+ head convs) for 128 channels; other shapes use MIOpen convolutions + the fused epilogue
         self.tower = (bool(tower) and mode == "bf16" and tuple(net.board_size) in ((6, 6), (8, 8), (12, 12))
                       and net.conv1.out_channels == 128 and len(net.res_blocks) <= 10)
-        if mode == "f16x3":
-            if tuple(net.board_size) not in H3_BOARDS or net.conv1.out_channels != 128 or len(net.res_blocks) > 10 \
-                    or net.policy_conv.out_channels != 32:
-                raise ValueError("f16x3 needs 6x6, 8x8 or 12x12 boards, 128 channels, at most 10 residual blocks")
-            (wq, bq, kw), (hw, hb, kh) = pack_tower_h3(net), pack_heads_h3(net)
-            self.h3_exps = (kw, kh, ACT_EXP)     # weights x 2^kw, head weights x 2^kh, activations x 2^ACT_EXP
-            self.h3_w = torch.cat([wq, hw]).contiguous().to(self.device)
-            self.h3_b = torch.cat([bq, hb]).contiguous().to(self.device)
+        if mode in ("f16x3", "f16x3r"):
+            if not f16x3_covers(net):
+                raise ValueError("f16x3 needs a board of at most 144 cells, 32/64/96/128 channels, at most 10 residual blocks, 32-channel heads")
+            dev = self.device
+            R, C = net.board_size
             self.h3_layers = 1 + 2 * len(net.res_blocks)
-            # the same weights in wave-major order for the register-ring kernel (csrc/yy_tower_h3r.hip), the form used whenever
-            # the batch fills the chip; 8x8 batches of <= H3R_MIN_ROWS boards take the one-board-per-workgroup LDS-ring form
-            self.h3r_w = pack_tower_h3r(net)[0].to(self.device)
-            self.h3r_hw = pack_heads_h3r(net)[0].to(self.device)
-            self.h3r_min_rows = H3R_MIN_ROWS if tuple(net.board_size) == (8, 8) else 0
-            self.auto_form = tuple(net.board_size) == (8, 8)
-            f32 = lambda t: t.detach().float().contiguous().to(self.device)
-            self.pfc_wt, self.pfc_b = f32(net.policy_fc.weight.t()), f32(net.policy_fc.bias)
-            self.vfc1_wt, self.vfc1_b = f32(net.value_fc1.weight.t()), f32(net.value_fc1.bias)
+            # the general kernel (csrc/yy_tower_g.hip): weights in MFMA operand order, the kernel forms for this board
+            wq, bq, kw = pack_tower_g(net)
+            hw, hb, kh = pack_heads_g(net)
+            self.g_w, self.g_b, self.g_hw, self.g_hb = wq.to(dev), bq.to(dev), hw.to(dev), hb.to(dev)
+            self.g_exps = (kw, kh, ACT_EXP)       # weights x 2^kw, head weights x 2^kh, activations x 2^ACT_EXP
+            self.g_big, self.g_small = tower_g_forms(R * C, net.conv1.out_channels)
+            self.g_split = G_SPLIT_WG * self.g_small[1]
+            # policy_fc + value_fc1 as one split-f16 GEMM kernel (csrc/yy_fc_heads.hip), fixed summation order per output
+            fw, fb, jobs, kf = pack_fc_heads(net)
+            self.fc_w, self.fc_b, self.fc_jobs, self.fc_exps = fw.to(dev), fb.to(dev), jobs.to(dev), (kf, ACT_EXP)
+            self.n_actions, self.n_hidden = net.policy_fc.out_features, net.value_fc1.out_features
+            f32 = lambda t: t.detach().float().contiguous().to(dev)
             self.fc2_w, self.fc2_b = f32(net.value_fc2.weight.reshape(-1)), f32(net.value_fc2.bias.reshape(1))
+            self.use_h3r = False
+            if mode == "f16x3r":                  # A/B partner: the 32x32x16 register-ring tower of round 2 (6x6 / 8x8 / 12x12, 128 channels)
+                if tuple(net.board_size) not in H3_BOARDS or net.conv1.out_channels != 128:
+                    raise ValueError("f16x3r needs 6x6, 8x8 or 12x12 boards and 128 channels")
+                self.h3_b = torch.cat([pack_tower_h3(net)[1], pack_heads_h3(net)[1]]).contiguous().to(dev)
+                self.h3r_w = pack_tower_h3r(net)[0].to(dev)
+                self.h3r_hw = pack_heads_h3r(net)[0].to(dev)
+                kw_r, kh_r = pack_tower_h3(net)[2], pack_heads_h3(net)[2]
+                self.h3_exps = (kw_r, kh_r, ACT_EXP)
+                self.use_h3r = True
+                self.mode = mode = "f16x3"
             self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
             self.supports_static = True          # __call__(..., static=True): results in buffers kept per batch size
             self._static = {}
-            self.use_h3r = True
             self.tower = False
-            # a row's (policy, value) is a function of that row's planes alone, bit for bit: the tower computes each board in a
-            # fixed order whatever its position in the batch (tests/test_gpu_network.py::test_split_f16_compaction_is_exact),
-            # so the search may reuse the value of a childless node instead of evaluating it again (YY_FLAG_REUSE_PASS_VALUE)
+            # A row's (policy, value) is a function of that row's planes alone, bit for bit, BY CONSTRUCTION: the tower computes
+            # each board in a fixed order whatever its workgroup form or position in the batch, and the FC heads are our own
+            # fixed-order kernel (no library GEMM whose tiling could follow the batch size).  Pinned by
+            # tests/test_gpu_network.py::test_evaluator_rows_do_not_depend_on_the_batch.  The search may therefore reuse
+            # evaluations across launches of different sizes (YY_FLAG_REUSE_*, the opening book).
             self.row_independent = True
             return
-        if mode in ("fp32t", "bf16x3"):
+        if mode == "fp32t":
             if tuple(net.board_size) != (8, 8) or net.conv1.out_channels != 128 or len(net.res_blocks) > 11:
                 raise ValueError(mode + " needs 8x8 boards, 128 channels, at most 11 residual blocks")
-            wq, bq = pack_tower_f32(net) if mode == "fp32t" else pack_tower_x3(net)
+            wq, bq = pack_tower_f32(net)
             self.f32_w, self.f32_b = wq.to(self.device), bq.to(self.device)
             self.f32_layers = 1 + 2 * len(net.res_blocks)
             # float32 heads in four GEMM-shaped steps: both 1x1 head convs as ONE [G*64,128] x [128,64] product, then
@@ -450,40 +538,43 @@ class BatchedEvaluator:
         zero-filled tensors (four fill kernels per call less); the returned tensors are overwritten by the next call."""
         if self.mode == "f16x3":
             from . import engine
-            rows = n = pol = val = None
+            G = planes.shape[0]
+            K = 32 * planes.shape[2] * planes.shape[3]
+            rows = n = pol = val = feats = logits = hidden = None
             if static:
-                G = planes.shape[0]
                 buf = self._static.get(G)
                 if buf is None:
                     dev = planes.device
-                    buf = self._static[G] = (torch.zeros(G, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
-                                             torch.zeros((G, self.pfc_b.shape[0]), dtype=torch.float32, device=dev),
-                                             torch.zeros(G, dtype=torch.float32, device=dev))
-                rows, n, pol, val = buf
+                    z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
+                    buf = self._static[G] = (z(G, torch.int32), z(1, torch.int32), z((G, self.n_actions)), z(G), z((G, 2, K)),
+                                             z((G, self.n_actions)), z((G, self.n_hidden)))
+                rows, n, pol, val, feats, logits, hidden = buf
             if needs_eval is not None:
                 rows, n = engine.compact_rows(needs_eval, rows, n)
             else:
                 rows = n = None
-            if rows is not None and self.auto_form and self.h3r_min_rows < planes.shape[0] <= H3_AUTO_MAX_ROWS and self.use_h3r:
-                # a mid-size batch whose compacted launches may hold few rows: the form is chosen on the device per launch
-                feats = engine.tower_heads_forward_h3_auto(planes, self.h3_w, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers,
-                                                           self.h3_exps, rows, n, H3_AUTO_SPLIT)
-            elif planes.shape[0] > self.h3r_min_rows and self.use_h3r:
-                feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, self.h3_exps, rows, n)
+            if self.use_h3r:
+                feats = engine.tower_heads_forward_h3r(planes, self.h3r_w, self.h3r_hw, self.h3_b, self.h3_layers, self.h3_exps, rows, n, feats)
             else:
-                feats = engine.tower_heads_forward_h3(planes, self.h3_w, self.h3_b, self.h3_layers, self.h3_exps, rows, n)   # [G, 2, 32*cells] f32
-            logits = torch.addmm(self.pfc_b, feats[:, 0], self.pfc_wt)                                    # [G, A]
-            hidden = torch.addmm(self.vfc1_b, feats[:, 1], self.vfc1_wt)                                  # [G, 256]
+                tg = lambda form, gate, out: engine.tower_g(planes, self.g_w, self.g_b, self.h3_layers, self.g_exps, form[0], form[1],
+                                                            self.g_hw, self.g_hb, rows, n, out, gate)
+                if self.g_small == self.g_big or G > G_AUTO_MAX_WG * self.g_small[1] or (rows is None and G > self.g_split):
+                    feats = tg(self.g_big, (-1, 0x7FFFFFFF), feats)
+                elif G <= self.g_split:
+                    feats = tg(self.g_small, (-1, 0x7FFFFFFF), feats)
+                else:       # the live row count is only known on the device: both forms are enqueued, the gate picks one (same bits)
+                    feats = tg(self.g_small, (-1, self.g_split), feats)
+                    feats = tg(self.g_big, (self.g_split, 0x7FFFFFFF), feats)
+            logits, hidden = engine.fc_heads(feats, self.fc_w, self.fc_b, self.fc_jobs, self.n_actions, self.n_hidden, self.fc_exps, n,
+                                             logits, hidden)
             return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n, pol, val)
         if needs_eval is not None:
             raise ValueError(f"evaluator mode {self.mode} does not take needs_eval")
         if self.mode == "fp32":
             return self.net.predict_batch(planes)
-        if self.mode in ("fp32t", "bf16x3"):
+        if self.mode == "fp32t":
             from . import engine
-            n = self.net
-            tower = engine.tower_forward_f32 if self.mode == "fp32t" else engine.tower_forward_x3
-            x = tower(planes, self.f32_w, self.f32_b, self.f32_layers)           # NCHW view of [G,8,8,128] memory
+            x = engine.tower_forward_f32(planes, self.f32_w, self.f32_b, self.f32_layers)           # NCHW view of [G,8,8,128] memory
             G = x.shape[0]
             cells = x.shape[2] * x.shape[3]
             hc = torch.addmm(self.hconv_b, x.permute(0, 2, 3, 1).reshape(G * cells, -1), self.hconv_w)   # [G*cells, 64]
