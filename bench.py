@@ -12,8 +12,8 @@ Workload = config[1] of BASELINE.json: 8x8, 800 sims, 4096 concurrent games per 
 batch is in the steady state of continuous self-play.  value = positions/s over all ranks.
 
 The headline leg runs the evaluator at the REFERENCE's precision: `--nn f16x3` = the split-f16 tower
-(csrc/yy_tower_h3.hip: float32-accurate, identical visit counts to the reference's CPU float32 search on all
-64 golden roots -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 one more
+(csrc/yy_tower_g.hip + yy_fc_heads.hip: float32-accurate, identical visit counts to the reference's CPU float32 search on
+every golden root at 6x6, 8x8, 12x12 and three non-default shapes -- tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi).  At N=1 one more
 leg is timed in the same run and reported as an extra key of the same JSON line: `secondary` = the bf16
 tower (reduced precision: NOT the headline); `--oversubscribe G2` adds a leg with G2 concurrent games (`oversubscribed`);
 `with_evaluation_reuse` is the same workload with the engine's evaluation reuse on (off in the headline).
@@ -68,6 +68,9 @@ def parse():
                     help="legs with evaluation reuse also get a shared opening book: every position reachable with at most this "
                          "many stones, evaluated once before the timed region (0 = none; boards of at most 64 cells)")
     ap.add_argument("--reuse-steps", type=int, default=10, help="steps of the extra leg with evaluation reuse on (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --games concurrent games PER GPU; strong: --games in total, split over the ranks "
+                         "(SURVEY 8d config 3: 8 x 512)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -436,7 +439,7 @@ def make_roofline(args, eng, games):
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     tkey = dict(games=games, rows=args.rows, cols=args.cols, channels=args.channels, blocks=args.blocks)   # the tower launch
     key = dict(tkey, sims=args.sims, semantics=args.semantics)                                             # the tree kernel
-    traffic, src = pmc_traffic("r02_k_mcts_pmc.json", key)
+    traffic, src = pmc_traffic("r03_k_mcts_pmc.json", key)
     roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                  "traffic_source": src, "avg_launch_ms": k_ms, "launches_timed": n_launch,
@@ -447,7 +450,7 @@ def make_roofline(args, eng, games):
         _, name, flops, peak = tl
         ach = flops / (tower_ms * 1e-3) / 1e12
         mode = getattr(eng.evaluator, "mode", "")
-        traffic, src = pmc_traffic(f"r02_k_tower_{mode}_hbm_pmc.json", tkey)
+        traffic, src = pmc_traffic(f"r03_k_tower_{mode}_hbm_pmc.json", tkey)
         out = {"roofline": {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                             "frac": ach / peak, "traffic": traffic, "traffic_source": src, "avg_launch_ms": tower_ms,
                             "algorithmic_flops_per_launch": flops,
@@ -481,12 +484,12 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
         "metric": f"self-play positions/sec (+ MCTS node-expansions/sec) at {args.sims} sims, {args.rows}x{args.cols} board",
         "value": main_leg["positions"] / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.nn,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": args.nn,
         "dtype_note": FP32_GRADE.get(args.nn, "reduced-precision evaluator (the reference evaluates in float32)"),
         "data": "synthetic",
         "expansions_per_s": main_leg["evals"] / dt, "simulations_per_s": main_leg["sims_total"] / dt,
         "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
-                               f"per GPU, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
+                               f"{'per GPU' if args.scaling == 'weak' else 'in total (split over the ranks)'}, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
                                f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
                    "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
                    "evaluation_reuse": bool(main_leg.get("reuse", False)),
@@ -530,7 +533,10 @@ def main():
     dev = torch.device("cuda", local)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")      # where collectives run
 
-    main_leg = run_leg(args, args.nn, args.games, args.steps, args.warmup, rank, world, dist, cdev, with_roofline=True)
+    if args.scaling == "strong":
+        assert args.games % world == 0, "--scaling strong: --games must divide by the number of ranks"
+    per_rank = args.games if args.scaling == "weak" else args.games // world
+    main_leg = run_leg(args, args.nn, per_rank, args.steps, args.warmup, rank, world, dist, cdev, with_roofline=True)
     extra = {}
     default_workload = (args.games, args.rows, args.cols, args.sims, args.channels, args.blocks) == (4096, 8, 8, 800, 128, 10)
     if world == 1:
@@ -549,6 +555,17 @@ def main():
                                  "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
             s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated
             s["opening_book"] = leg.get("book")
+            if leg.get("book"):
+                # the book is evaluated once per network and serves a whole self-play run: config 2 plays its 4096 games to the
+                # end in ~53 steps, so these `steps` carry steps/53 of the build; the other two readings are alongside
+                b = leg["book"]["build_s"]
+                run_steps = 53.0
+                s["value_excluding_book_build"] = s["value"]
+                s["value_book_build_inside_these_steps"] = leg["positions"] / (leg["dt"] + b)
+                s["value"] = leg["positions"] / (leg["dt"] + b * leg["steps"] / run_steps)
+                s["value_note"] = ("positions/s with the opening book's build time charged pro rata: a book is built once per network and "
+                                   "serves a whole run (config 2 = ~%d steps); these %d steps carry %d/%d of its %.2f s" % (
+                                       run_steps, leg["steps"], leg["steps"], run_steps, b))
             # tree nodes expanded (Node.expand calls of the reference, mcts.py:397): by an evaluator row or from the cache
             s["node_expansions_per_s"] = (leg["evals"] + leg["served"]) / leg["dt"]
             extra["with_evaluation_reuse"] = s

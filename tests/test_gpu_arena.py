@@ -281,7 +281,7 @@ def test_bench_json_contract(tmp_path):
     assert cb["aliased_expansions_per_s"] > 0 and "one per host core" in cb["sample"]
     # the headline leg evaluates at the reference's precision; the reduced-precision figure is a labelled extra key
     assert d["dtype"] == "f16x3" and "float32" in d["dtype_note"] and d["config"]["nn_dtype"] == "f16x3"
-    assert "k_tower_h3" in rf["kernel"] and rf["bound"] == "mfma" and "traffic_source" in rf
+    assert "k_tower_g" in rf["kernel"] and rf["bound"] == "mfma" and "traffic_source" in rf
     assert "40 sims" in d["metric"] and "8x8" in d["metric"]
     sec = d["secondary"]
     assert sec["nn"] == "bf16" and sec["value"] > 0 and "REDUCED" in sec["note"]

@@ -17,7 +17,7 @@
 // the 64 rows (four 16-column blocks).  Features f32 [row][head][K] are staged through LDS in chunks of 128 k, split into
 // hi / lo on the way (rows of 256 B at a stride of 288 B: conflict-free for this MFMA's B-operand reads), double buffered,
 // one barrier per chunk; the weights of a slice ([k-step][wave][part][lane][8 f16], network.pack_fc_heads) go global ->
-// register in MFMA operand order, one k-step ahead.
+// register in MFMA operand order, one chunk (four k-steps) ahead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -66,16 +66,17 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
 
     // staging: thread t moves float4 #(t % 32) of rows t/32 + 8*i (i = 0..7) of the chunk
     const int sq = threadIdx.x & 31, sr = threadIdx.x >> 5;
-    f32x4 fr[8];
-    auto stage_load = [&](int c) {
+    auto stage_load = [&](f32x4 (&fr)[8], int c) {
         const int k = c * KC + sq * 4;
+        const int kc = k < K ? k : 0;                                             // unconditional loads (no branch between the
+        const float km = k < K ? 1.0f : 0.0f;                                     // prefetches); k >= K contributes zeros
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int row = min(r0 + sr + 8 * i, n_live - 1);                    // rows past the live count repeat the last one (never stored)
-            fr[i] = (k < K) ? *(const f32x4 *)(feats + ((size_t)row * 2 + job.head) * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            fr[i] = *(const f32x4 *)(feats + ((size_t)row * 2 + job.head) * K + kc) * km;
         }
     };
-    auto stage_store = [&](int s) {
+    auto stage_store = [&](const f32x4 (&fr)[8], int s) {
         unsigned char *base = lds + s * STAGE_BYTES + sq * 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -92,32 +93,66 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
 #pragma unroll
     for (int nb = 0; nb < 4; nb++) acc1[nb] = acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage_load(0);
-    f16x8 wh = __builtin_bit_cast(f16x8, *(const u32x4 *)wbase), wl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wbase + 1024));
-    stage_store(0);
-    __syncthreads();
-    for (int c = 0; c < n_chunks; c++) {
-        if (c + 1 < n_chunks) stage_load(c + 1);
-        const unsigned char *xs = lds + (c & 1) * STAGE_BYTES + n16 * RS + kg * 16;
+    // this wave's weight fragments of one chunk: [k-step 4]{hi, lo}; loaded a whole chunk (768 MFMA cycles) ahead
+    auto load_wc = [&](f16x8 (&w)[KC / 32][2], int c) {
 #pragma unroll
         for (int ks = 0; ks < KC / 32; ks++) {
-            const int nk = min(c * (KC / 32) + ks + 1, n_chunks * (KC / 32) - 1);    // next k-step (the last one re-reads itself)
-            const f16x8 nwh = __builtin_bit_cast(f16x8, *(const u32x4 *)(wbase + (size_t)nk * 8192));
-            const f16x8 nwl = __builtin_bit_cast(f16x8, *(const u32x4 *)(wbase + (size_t)nk * 8192 + 1024));
-            if (active) {
-#pragma unroll
-                for (int nb = 0; nb < 4; nb++) {
-                    const f16x8 xh = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + nb * 16 * RS + ks * 64));
-                    const f16x8 xl = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + PART_BYTES + nb * 16 * RS + ks * 64));
-                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc2[nb], 0, 0, 0);
-                    acc1[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc1[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a, 0, 0, 0);
-                }
-            }
-            wh = nwh;
-            wl = nwl;
+            const unsigned char *p = wbase + (size_t)(c * (KC / 32) + ks) * 8192;
+            w[ks][0] = __builtin_bit_cast(f16x8, *(const u32x4 *)p);
+            w[ks][1] = __builtin_bit_cast(f16x8, *(const u32x4 *)(p + 1024));
         }
-        if (c + 1 < n_chunks) stage_store((c + 1) & 1);
+    };
+    // One chunk: 16 groups (k-step, row block) of {2 ds_read_b128, 3 MFMAs}; the fragments of group g + 4 are requested right
+    // after the MFMAs of group g (a rotating window of four), so the LDS latency is paid once per chunk, not once per group.
+    auto compute = [&](const f16x8 (&w)[KC / 32][2], int stage) {
+        if (!active) return;
+        const unsigned char *xs = lds + stage * STAGE_BYTES + n16 * RS + kg * 16;
+        constexpr int NG = (KC / 32) * 4, P = 4;
+        f16x8 xh[P], xl[P];
+        auto rd = [&](int g, int slot) {
+            const int ks = g >> 2, nb = g & 3;
+            xh[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + nb * 16 * RS + ks * 64));
+            xl[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + PART_BYTES + nb * 16 * RS + ks * 64));
+        };
+#pragma unroll
+        for (int g = 0; g < P; g++) rd(g, g);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * P, 0);      // the window's first fill stays in front of the first MFMA
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int ks = g >> 2, nb = g & 3, slot = g % P;
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][1], xh[slot], acc2[nb], 0, 0, 0);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][0], xh[slot], acc1[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][0], xl[slot], a, 0, 0, 0);
+            if (g + P < NG) rd(g + P, slot);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    };
+    // Software pipeline, two chunks per trip so that every buffer has a fixed name: the feature rows of chunk c + 3 and the
+    // weight fragments of chunk c + 2 are requested while chunk c computes, i.e. two chunks (~1 us) before they are used --
+    // the feature tensor was just written by the tower launch and comes from the Infinity Cache / HBM.  Chunk indices past
+    // the end are clamped (they re-read the last chunk; never stored, never multiplied).
+    const int last = n_chunks - 1;
+    f32x4 f0[8], f1[8];                      // f0: the odd chunk after the one computing, f1: the even chunk after that
+    f16x8 w0[KC / 32][2], w1[KC / 32][2];    // w0: weights of the even chunk computing / to come, w1: of the odd one
+    stage_load(f1, 0);
+    load_wc(w0, 0);
+    stage_load(f0, min(1, last));
+    load_wc(w1, min(1, last));
+    stage_store(f1, 0);
+    stage_load(f1, min(2, last));
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c += 2) {
+        compute(w0, 0);                                          // chunk c (even) from stage 0
+        if (c + 1 < n_chunks) stage_store(f0, 1);                // chunk c + 1 -> stage 1
+        stage_load(f0, min(c + 3, last));
+        load_wc(w0, min(c + 2, last));
+        __syncthreads();
+        if (c + 1 >= n_chunks) break;
+        compute(w1, 1);                                          // chunk c + 1 (odd) from stage 1
+        if (c + 2 < n_chunks) stage_store(f1, 0);                // chunk c + 2 -> stage 0
+        stage_load(f1, min(c + 4, last));
+        load_wc(w1, min(c + 3, last));
         __syncthreads();
     }
     if (!active) return;
