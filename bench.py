@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --games concurrent games PER GPU; strong: --games in total, split over the ranks "
                          "(SURVEY 8d config 3: 8 x 512)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="HIP streams the rank's games are cut over (self_play.SelfPlayLanes): one lane's evaluator launch fills the "
+                         "compute units the other lane's partly empty last round of workgroups leaves idle; 1 = one lockstep batch")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -87,6 +90,14 @@ def parse():
 def stagger_start(eng, seed):
     """Advance game g by (g mod 48) uniformly random legal plies with the HIP rules kernels, so the
     batch holds openings, middle games and endings like continuous self-play does."""
+    if hasattr(eng, "lanes"):                  # SelfPlayLanes: every lane, with its own seed and its own global game indices
+        K = len(eng.lanes)
+        for k, lane in enumerate(eng.lanes):
+            with lane._on_stream():
+                stagger_start(lane, seed + 7919 * k)
+                lane.game_id = lane.game_id * K + k
+        torch.cuda.synchronize()
+        return
     from yinyang_game_alphazero_amd import engine as E
     G, dev = eng.G, eng.device
     gen = torch.Generator(device=dev)
@@ -158,16 +169,15 @@ class HipEventTimer:
         return tot / max(self.i, 1), self.i
 
 
-def tower_launcher(eng):
-    """(callable launching the evaluator's dominant kernel ALONE on the live leaf batch, kernel name, algorithmic FLOPs per
+def tower_launcher(eng, planes):
+    """(callable launching the evaluator's dominant kernel ALONE on the leaf batch `planes`, kernel name, algorithmic FLOPs per
     launch, MFMA peak it is priced against) or None when the evaluator has no hand-written tower."""
     from yinyang_game_alphazero_amd import engine as E
-    ev, G = eng.evaluator, eng.G
+    ev, G = eng.evaluator, planes.shape[0]
     cells, blocks = eng.R * eng.C, len(ev.net.res_blocks)
     body = 2 * blocks * (2 * 9 * 128 * 128 * cells)
     heads = 2 * 128 * 64 * cells
     mode = getattr(ev, "mode", "")
-    planes = eng.ctx.planes
     if mode == "f16x3":
         stem = 2 * 9 * 5 * ev.net.conv1.out_channels * cells
         ch = ev.net.conv1.out_channels
@@ -207,33 +217,40 @@ def tower_launcher(eng):
 
 
 def roofline_pass(eng):
-    """One more move of the SAME workload, launched eagerly (same kernels as the graph replays) with HIP
-    events around every fused tree-kernel launch; returns (mean kernel ms, launches, device counters of
-    exactly those launches, mean evaluator-forward ms, move ms, mean dominant-kernel ms or None)."""
-    eng.search.use_graph, eng.search.graph = False, None
-    eng.ctx.reset_counters()
-    timer = HipEventTimer(eng.sims)
-    eng.search.timer = timer
-    t0 = torch.cuda.Event(enable_timing=True)
-    t1 = torch.cuda.Event(enable_timing=True)
-    t0.record()
-    eng.play_move()
-    t1.record()
-    eng.search.timer = None
+    """One more move of the SAME workload, launched eagerly (same kernels as the graph replays) with HIP events around every
+    fused tree-kernel launch of ONE lane; returns (mean kernel ms, launches, that lane's device counters of exactly those
+    launches, mean evaluator-forward ms, move ms, mean dominant-kernel ms or None, live launch or None, lane games).  The
+    evaluator and its dominant kernel are timed on the leaf batch of ALL lanes together (= the configuration's G rows)."""
+    lanes = getattr(eng, "lanes", [eng])
+    lane = lanes[0]
+    torch.cuda.synchronize()
+    lane.search.use_graph, lane.search.graph = False, None
+    lane.ctx.reset_counters()
+    timer = HipEventTimer(lane.sims)
+    lane.search.timer = timer
+    with lane._on_stream():
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        lane.play_move()
+        t1.record()
+    lane.search.timer = None
     k_ms, n = timer.mean_ms()
-    counters = eng.ctx.status()
+    counters = lane.ctx.status()
     move_ms = t0.elapsed_time(t1)
-    # evaluator forward alone (every row), same batch
+    planes = torch.cat([l.ctx.planes for l in lanes]).contiguous()
+    needs = torch.cat([l.ctx.needs_eval for l in lanes]).contiguous()
+    # evaluator forward alone (every row), the whole leaf batch
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
     for _ in range(reps):
-        eng.evaluator(eng.ctx.planes)
+        eng.evaluator(planes)
     e1.record()
     torch.cuda.synchronize()
     tower_ms, live = None, None
-    tl = tower_launcher(eng)
+    tl = tower_launcher(eng, planes)
     if tl is not None:      # the dominant kernel alone: HIP events on its launch stream
         tt = HipEventTimer(reps)
         for _ in range(reps):
@@ -242,16 +259,16 @@ def roofline_pass(eng):
             tt.stop()
         tower_ms, _ = tt.mean_ms()
         if getattr(eng.evaluator, "supports_compaction", False):
-            # the launch as the lockstep step issues it: only the rows of the pending leaf batch that need an evaluation
+            # the same kernel on only the rows of the pending leaf batch that need an evaluation
             from yinyang_game_alphazero_amd import engine as E
-            rows, n_rows = E.compact_rows(eng.ctx.needs_eval)
+            rows, n_rows = E.compact_rows(needs)
             tt = HipEventTimer(reps)
             for _ in range(reps):
                 tt.start()
                 tl[0](rows, n_rows)
                 tt.stop()
             live = (tt.mean_ms()[0], int(n_rows.item()))
-    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms, live
+    return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms, live, lane.G, planes
 
 
 def algorithmic_bytes(counters, G, A, n_steps, nw):
@@ -382,7 +399,7 @@ def timed_region(eng, steps, warmup, rank, world, dist, cdev, sims, capacity=Non
 
 def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofline, reuse=None):
     import yinyang_game_alphazero_amd as pkg
-    from yinyang_game_alphazero_amd.self_play import SelfPlayEngine, example_capacity
+    from yinyang_game_alphazero_amd.self_play import SelfPlayLanes, example_capacity
     dev = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(0)
     game = pkg.YinYangGame(args.rows, args.cols)
@@ -396,7 +413,7 @@ def run_leg(args, nn, games, steps, warmup, rank, world, dist, cdev, with_roofli
         book = pkg.engine.OpeningBook(args.rows, args.cols, evaluator, args.book_stones, device=dev)
         torch.cuda.synchronize()
         book_s = time.perf_counter() - tb
-    eng = SelfPlayEngine(game, evaluator, num_simulations=args.sims, concurrent_games=games, opening_book=book,
+    eng = SelfPlayLanes(game, evaluator, num_simulations=args.sims, concurrent_games=games, opening_book=book, lanes=args.lanes,
                          board_semantics=args.semantics, reference_quirks=args.quirks,
                          use_graph=not args.no_graph, seed=1000, device=dev,
                          first_game_index=rank, game_index_stride=world,
@@ -431,21 +448,22 @@ def pmc_traffic(name, key):
 
 
 def make_roofline(args, eng, games):
-    k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms, live = roofline_pass(eng)
+    k_ms, n_launch, kc, nn_ms, eager_move_ms, tower_ms, live, lane_games, planes = roofline_pass(eng)
     A = args.rows * args.cols
     nw = (A + 63) // 64
-    # the counters cover the whole move = n_launch + 1 selections (the first one runs before the timed fused steps)
-    bytes_per_launch, shape = algorithmic_bytes(kc, games, A, n_launch + 1, nw)
+    # the counters cover one lane's whole move = n_launch + 1 selections (the first one runs before the timed fused steps)
+    bytes_per_launch, shape = algorithmic_bytes(kc, lane_games, A, n_launch + 1, nw)
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     tkey = dict(games=games, rows=args.rows, cols=args.cols, channels=args.channels, blocks=args.blocks)   # the tower launch
-    key = dict(tkey, sims=args.sims, semantics=args.semantics)                                             # the tree kernel
+    key = dict(tkey, games=lane_games, sims=args.sims, semantics=args.semantics)                           # the tree kernel (one lane's launch)
     traffic, src = pmc_traffic("r03_k_mcts_pmc.json", key)
-    roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode)", "achieved": achieved,
+    roof_tree = {"bound": "hbm", "kernel": "k_mcts (fused expand+backup+select+rules+encode), one lane of %d games per launch" % lane_games,
+                 "achieved": achieved,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                  "traffic_source": src, "avg_launch_ms": k_ms, "launches_timed": n_launch,
                  "algorithmic_bytes_per_launch": bytes_per_launch, **shape}
     out = {"roofline": roof_tree}
-    tl = tower_launcher(eng)
+    tl = tower_launcher(eng, planes)
     if tl is not None and tower_ms is not None:
         _, name, flops, peak = tl
         ach = flops / (tower_ms * 1e-3) / 1e12
@@ -493,7 +511,7 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
                                f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
                    "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
                    "evaluation_reuse": bool(main_leg.get("reuse", False)),
-                   "parallelism": f"episode-sharded x{world}", "hipgraph": not args.no_graph},
+                   "parallelism": f"episode-sharded x{world}", "lanes_per_gpu": args.lanes, "hipgraph": not args.no_graph},
         "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
         **roof, **(extra or {}),
     }

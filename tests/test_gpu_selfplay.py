@@ -517,3 +517,62 @@ def test_game_transcripts_do_not_depend_on_slot_batch_or_world_size(pkg):
         for g in ref:
             for a, b in zip(ref[g], other[g]):
                 assert np.array_equal(a, b), g
+
+
+def test_lanes_play_the_same_games(pkg):
+    """SelfPlayLanes (the batch cut into lanes on separate HIP streams, moves enqueued back to back and pipelined) plays the
+    same games as one SelfPlayEngine: every game's (states, pi, z) identical for 1, 2 and 3 lanes, with the exact hash
+    evaluator and with the live split-f16 evaluator + evaluation reuse (static per-stream buffers, per-lane caches); the lanes
+    split the global game indices as lane k of K = first + (k + j*K) * stride, also inside a 2-rank sharding."""
+    import torch
+    from hash_eval import hash_eval_torch
+    game = pkg.YinYangGame(6, 6)
+
+    def by_game(ex):
+        out = {}
+        gid, ply = ex["game_id"].cpu().numpy(), ex["ply"].cpu().numpy()
+        st, pi, z = ex["states"].cpu().numpy(), ex["policies"].cpu().numpy(), ex["values"].cpu().numpy()
+        for g in np.unique(gid):
+            sel = np.flatnonzero(gid == g)
+            sel = sel[np.argsort(ply[sel])]
+            out[int(g)] = (st[sel], pi[sel], z[sel])
+        return out
+
+    def same(a, b):
+        assert sorted(a) == sorted(b)
+        for g in a:
+            for x, y in zip(a[g], b[g]):
+                assert np.array_equal(x, y), g
+
+    ev = lambda planes: hash_eval_torch(planes, 10, 11)
+    one = pkg.SelfPlayEngine(game, ev, num_simulations=20, concurrent_games=48, seed=1000)
+    ref = by_game(one.run(80))
+    one.close()
+    assert sorted(ref) == list(range(80))
+    for K in (1, 2, 3):
+        lanes = pkg.SelfPlayLanes(game, ev, num_simulations=20, concurrent_games=30, lanes=K, seed=1000, row_tiers=(4, 8))
+        assert len(lanes.lanes) == K and lanes.G == 30
+        got = by_game(lanes.run(80))
+        assert lanes.games_finished == 80 and lanes.n_alive == 0
+        lanes.close()
+        same(ref, got)
+    two = {}
+    for r in (0, 1):
+        lanes = pkg.SelfPlayLanes(game, ev, num_simulations=20, concurrent_games=16, lanes=2, seed=1000, first_game_index=r, game_index_stride=2)
+        two.update(by_game(lanes.run(40)))
+        lanes.close()
+    same(ref, two)
+    # live evaluator (static buffers per stream) + evaluation reuse + a shared opening book
+    torch.manual_seed(0)
+    net = pkg.YinYangNeuralNetwork(game, 32, 1).cuda().eval()
+    evn = pkg.BatchedEvaluator(net)
+    assert evn.mode == "f16x3"
+    one = pkg.SelfPlayEngine(game, evn, num_simulations=24, concurrent_games=40, seed=5)
+    ref = by_game(one.run(56))
+    one.close()
+    lanes = pkg.SelfPlayLanes(game, evn, num_simulations=24, concurrent_games=40, lanes=2, seed=5, opening_book=2)
+    assert lanes.reuse_transpositions and lanes.book is not None
+    got = by_game(lanes.run(56))
+    moves = [lanes.play_move() for _ in range(2)] if False else None
+    lanes.close()
+    same(ref, got)

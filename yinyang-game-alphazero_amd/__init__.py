@@ -19,7 +19,7 @@ def __getattr__(name):
         "YinYangNeuralNetwork": ".network", "BatchedEvaluator": ".network",
         "MCTS": ".mcts", "Node": ".mcts",
         "SelfPlayWorker": ".self_play", "SelfPlayManager": ".self_play",
-        "generate_self_play_data": ".self_play", "SelfPlayEngine": ".self_play",
+        "generate_self_play_data": ".self_play", "SelfPlayEngine": ".self_play", "SelfPlayLanes": ".self_play",
         "training": ".training", "AlphaZeroTrainer": ".training", "TrainingDataQueue": ".training",
         "TrainingPipeline": ".training", "run_training_pipeline": ".training", "augment_batch": ".training",
         "DataProcessor": ".training", "create_dataset_from_games": ".training",

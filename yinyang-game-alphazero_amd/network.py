@@ -534,19 +534,22 @@ class BatchedEvaluator:
     def __call__(self, planes, needs_eval=None, static=False):
         """needs_eval (uint8 [G], modes with `supports_compaction` only): evaluate just the flagged rows -- the tower launch
         gathers them, the other rows of the returned (policy, value) must not be read.
-        static (f16x3): write the row list and the results into buffers the evaluator keeps per batch size instead of fresh
-        zero-filled tensors (four fill kernels per call less); the returned tensors are overwritten by the next call."""
+        static (f16x3): write the row list and the results into buffers the evaluator keeps per (batch size, owner) instead of fresh
+        zero-filled tensors (four fill kernels per call less); the returned tensors are overwritten by the owner's next call.
+        True = one shared owner; any other hashable value = that owner's private buffers (one per LockstepSearch: searches on
+        different HIP streams must not share them -- a stream id would not do, graph captures share one capture stream)."""
         if self.mode == "f16x3":
             from . import engine
             G = planes.shape[0]
             K = 32 * planes.shape[2] * planes.shape[3]
             rows = n = pol = val = feats = logits = hidden = None
             if static:
-                buf = self._static.get(G)
+                key = (G, 0 if static is True else static)             # static = an owner token: engines on different streams must not share buffers
+                buf = self._static.get(key)
                 if buf is None:
                     dev = planes.device
                     z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
-                    buf = self._static[G] = (z(G, torch.int32), z(1, torch.int32), z((G, self.n_actions)), z(G), z((G, 2, K)),
+                    buf = self._static[key] = (z(G, torch.int32), z(1, torch.int32), z((G, self.n_actions)), z(G), z((G, 2, K)),
                                              z((G, self.n_actions)), z((G, self.n_hidden)))
                 rows, n, pol, val, feats, logits, hidden = buf
             if needs_eval is not None:

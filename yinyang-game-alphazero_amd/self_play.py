@@ -64,7 +64,7 @@ class LockstepSearch:
         if compact and getattr(self.evaluator, "supports_compaction", False):
             kw["needs_eval"] = ctx.needs_eval if rows >= ctx.G else ctx.needs_eval[:rows]
         if getattr(self.evaluator, "supports_static", False):
-            kw["static"] = True                    # the results are consumed by the tree kernel before the next call
+            kw["static"] = id(self)                # private buffers: the results are consumed by the tree kernel before this search's next call
         if rows >= ctx.G:
             return self.evaluator(ctx.planes, **kw)
         policy, value = self.evaluator(ctx.planes[:rows], **kw)
@@ -126,7 +126,7 @@ class SelfPlayEngine:
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
                  device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None,
                  reuse_pass_value=None, reuse_transpositions=None, keep_evaluations=None,
-                 opening_book=None):
+                 opening_book=None, stream=None):
         """reuse_pass_value / reuse_transpositions / keep_evaluations: None = on when the boards are copied and the evaluator
         declares `row_independent` (the split-f16 evaluator does).  The reference asks the network for every leaf: a node
         without legal moves again on every visit (ai/mcts.py:93-95, 371-397), a position another move order of the same search
@@ -151,6 +151,8 @@ class SelfPlayEngine:
         self.rowcol = bool(getattr(game, "rowcol_rule", False))
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.evaluator = evaluator
+        self.stream = stream                       # HIP stream every launch of this engine goes to (None: the caller's current one)
+        self._pending = None                       # a move enqueued by enqueue_move() and not yet finished
         if reuse_pass_value is None:
             reuse_pass_value = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
         if reuse_transpositions is None:
@@ -249,11 +251,40 @@ class SelfPlayEngine:
         self._start_games(idx[:room])
 
     # ---- one lockstep move for every live game (self_play.py:91-192)
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def play_move(self):
-        """Every per-move decision is taken on the device with fixed-shape masked operations; the host reads ONE small
-        statistics tensor at the end of the move (positions searched, games finished) and, when games finished, the list of
-        their slots.  Random draws come from the per-game counter streams of csrc/yy_selfplay.hip, so a game's noise and moves
-        depend only on (seed, global game index, ply)."""
+        """One lockstep move of every live game: enqueue_move() + finish_move()."""
+        self.enqueue_move()
+        return self.finish_move()
+
+    def finish_move(self):
+        """Waits for the move enqueue_move() put on the engine's stream, reads its one small statistics record (positions
+        searched, games finished) and, when games finished, labels their examples and refills their slots."""
+        assert self._pending is not None, "finish_move() without enqueue_move()"
+        host, event, fin, fin_res, fin_player = self._pending
+        self._pending = None
+        event.synchronize()
+        n_pos, n_fin = int(host[0]), int(host[1])
+        self.positions += n_pos
+        if n_fin:
+            with self._on_stream():
+                self._finalize(fin, fin_res, fin_player)
+        return n_pos
+
+    def enqueue_move(self):
+        """Every per-move decision is taken on the device with fixed-shape masked operations and ENQUEUED on the engine's
+        stream without waiting: the host reads ONE small statistics record per move, in finish_move().  Random draws come from the
+        per-game counter streams of csrc/yy_selfplay.hip, so a game's noise and moves depend only on (seed, global game index,
+        ply).  Between the two calls the host is free to enqueue the moves of other engines on other streams
+        (SelfPlayLanes): their kernels fill the compute units this engine's partly empty last round of workgroups leaves idle."""
+        assert self._pending is None, "enqueue_move() twice without finish_move()"
+        with self._on_stream():
+            self._enqueue_move()
+
+    def _enqueue_move(self):
         dev, G = self.device, self.G
         if self.compact_tail and self.games_started >= self.games_target:      # the batch is draining
             need = next(t for t in self.tiers if t >= self.n_alive)
@@ -315,18 +346,24 @@ class SelfPlayEngine:
         fin |= done
         fin_res = torch.where(done, ended, fin_res)
         fin_player = torch.where(done, self.players, fin_player)
-        stats = torch.stack([searching.sum(), fin.sum()]).cpu()                # the move's one host read
-        n_pos, n_fin = int(stats[0]), int(stats[1])
-        self.positions += n_pos
-        if n_fin:
-            self._finalize(fin, fin_res, fin_player)
-        return n_pos
+        stats = torch.stack([searching.sum(), fin.sum()])                      # the move's one host read, taken in finish_move()
+        if getattr(self, "_stats_host", None) is None:
+            self._stats_host = torch.zeros(2, dtype=stats.dtype).pin_memory()
+        self._stats_host.copy_(stats, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._pending = (self._stats_host, event, fin, fin_res, fin_player)
+
+    def begin_run(self, num_games):
+        """Arm the engine for `num_games` more games: the first ones start in the free slots, the others as slots free up."""
+        with self._on_stream():
+            self.games_target = self.games_started + int(num_games)
+            free = (~self.alive).nonzero(as_tuple=True)[0]
+            self._start_games(free[: int(num_games)])
 
     def run(self, num_games, progress=None):
         """Play `num_games` games to completion; returns the examples (device tensors)."""
-        self.games_target = self.games_started + int(num_games)
-        free = (~self.alive).nonzero(as_tuple=True)[0]
-        self._start_games(free[: int(num_games)])
+        self.begin_run(num_games)
         moves = 0
         while self.n_alive > 0:
             self.play_move()
@@ -350,6 +387,112 @@ class SelfPlayEngine:
 
     def close(self):
         self.ctx.close()
+
+
+class _LaneCounters:
+    """ctx-like view over the lanes' tree contexts: reset_counters() / status() summed over the lanes."""
+
+    def __init__(self, lanes):
+        self.lanes = lanes
+
+    def reset_counters(self):
+        for ln in self.lanes:
+            with ln._on_stream():
+                ln.ctx.reset_counters()
+
+    def status(self):
+        tot = {}
+        for ln in self.lanes:
+            for k, v in ln.ctx.status().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+
+class SelfPlayLanes:
+    """K independent SelfPlayEngine lanes of G / K games each on K HIP streams of ONE GPU, their moves enqueued back to back.
+
+    Why: a lockstep step's evaluator launch holds only the leaves that need an evaluation -- ~3 800 of 4 096 without evaluation
+    reuse, ~800 with it -- and a tower workgroup occupies a whole compute unit for the ~0.2-0.4 ms its boards take, so the last
+    round of workgroups of every launch leaves compute units idle until the launch ends (402 two-board workgroups on 256 CUs =
+    1.57 rounds = 2).  Games are independent, so the batch is cut into lanes whose steps are enqueued on separate streams: while
+    one lane's launch drains, the other lane's workgroups take the free compute units -- the chip sees one continuous flow of
+    workgroups instead of rounds.  A game's transcript depends only on (seed, global game index), never on its lane or slot,
+    so the games played are the same as a single engine's (tests/test_gpu_selfplay.py::test_lanes_play_the_same_games).
+    Lane k of K plays the games first_game_index + (k + j*K) * game_index_stride, j = 0, 1, ..."""
+
+    def __init__(self, game, evaluator, num_simulations=800, concurrent_games=4096, lanes=2, seed=0, device=None,
+                 first_game_index=0, game_index_stride=1, opening_book=None, **engine_kwargs):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        K = max(1, min(int(lanes), int(concurrent_games)))
+        self.game, self.evaluator, self.sims = game, evaluator, int(num_simulations)
+        if isinstance(opening_book, int):           # one book, shared read-only by every lane
+            R, C = game.getBoardSize()
+            opening_book = (engine.OpeningBook(R, C, evaluator, opening_book, rowcol=bool(getattr(game, "rowcol_rule", False)),
+                                               device=self.device) if opening_book > 0 else None)
+        self.book = opening_book
+        self.lanes = []
+        for k in range(K):
+            g_k = concurrent_games // K + (1 if k < concurrent_games % K else 0)
+            import contextlib
+            with torch.cuda.device(self.device):
+                st = torch.cuda.Stream(device=self.device) if K > 1 else None
+            # the lane's tensors are allocated under its own stream, so the caching allocator never recycles one of them
+            # for another stream while this stream still uses it
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                self.lanes.append(SelfPlayEngine(game, evaluator, num_simulations=num_simulations, concurrent_games=g_k, seed=seed,
+                                                 device=self.device, first_game_index=first_game_index + k * game_index_stride,
+                                                 game_index_stride=K * game_index_stride, opening_book=opening_book, stream=st,
+                                                 **engine_kwargs))
+        torch.cuda.synchronize(self.device)      # evaluator weights / the book were written on the caller's stream
+        ln = self.lanes[0]
+        self.G = sum(l.G for l in self.lanes)
+        self.R, self.C, self.A, self.T = ln.R, ln.C, ln.A, ln.T
+        self.reuse_pass_value, self.reuse_transpositions, self.keep_evaluations = ln.reuse_pass_value, ln.reuse_transpositions, ln.keep_evaluations
+        self.ctx = _LaneCounters(self.lanes)
+
+    positions = property(lambda self: sum(l.positions for l in self.lanes))
+    games_finished = property(lambda self: sum(l.games_finished for l in self.lanes))
+    n_alive = property(lambda self: sum(l.n_alive for l in self.lanes))
+
+    def play_move(self):
+        """One lockstep move of every lane: all lanes' moves are enqueued on their streams, then finished in turn."""
+        live = [l for l in self.lanes if l.n_alive > 0]
+        for l in live:
+            l.enqueue_move()
+        return sum(l.finish_move() for l in live)
+
+    def run(self, num_games, progress=None):
+        """Play `num_games` games to completion, the lanes' moves pipelined (a lane's next move is enqueued as soon as its last
+        one has been read back, while the other lanes' queued steps keep the GPU busy); returns the examples."""
+        K = len(self.lanes)
+        for k, l in enumerate(self.lanes):
+            l.begin_run(shard_games(int(num_games), k, K)[0])
+        live = [l for l in self.lanes if l.n_alive > 0]
+        for l in live:
+            l.enqueue_move()
+        moves = 0
+        while live:
+            for l in list(live):
+                l.finish_move()
+                if l.n_alive > 0:
+                    l.enqueue_move()
+                else:
+                    live.remove(l)
+            moves += 1
+            if progress and moves % 10 == 0:
+                progress(self)
+        self.ctx.status()            # per-game search errors are sticky on the device: any failure of any move raises here
+        return self.collect()
+
+    def collect(self):
+        torch.cuda.synchronize(self.device)
+        parts = [l.collect() for l in self.lanes]
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        for l in self.lanes:
+            l.close()
 
 
 # =============================================================================== multi-GPU sharding + gather
@@ -540,10 +683,11 @@ class SelfPlayManager:
                  temperature_threshold=10, dirichlet_alpha=0.3, dirichlet_epsilon=0.25, cpuct=1.0,
                  mcts_parallel=1, concurrent_games=4096, board_semantics="copied", reference_quirks=False,
                  nn_mode="auto", seed=0, num_channels=128, num_res_blocks=10, evaluation_reuse=None,
-                 opening_book_stones=None):
+                 opening_book_stones=None, lanes=None):
         """evaluation_reuse: None = the engine's default (on for copied boards with the float32-accurate evaluator: pass values +
         per-game evaluation cache, SelfPlayEngine); False = the network is asked for every leaf like the reference."""
         self.evaluation_reuse = evaluation_reuse
+        self.lanes = lanes                 # HIP streams the rank's games are cut over (SelfPlayLanes); None = 2 from 512 slots on
         # None = 8 stones when it pays: evaluation reuse on, a board of at most 64 cells (770 k positions at 8x8: ~1.5 s to build)
         # and at least 1024 games for this rank; 0 = no book
         self.opening_book_stones = opening_book_stones
@@ -573,8 +717,10 @@ class SelfPlayManager:
             auto = (self.evaluation_reuse is not False and self.board_semantics == "copied" and mine >= 1024
                     and self.game.getActionSize() <= 64 and getattr(evaluator, "row_independent", False))
             book = 8 if auto else 0
-        eng = SelfPlayEngine(self.game, evaluator, num_simulations=self.num_simulations, opening_book=int(book),
-                             concurrent_games=max(1, min(self.concurrent_games, mine)), cpuct=self.cpuct,
+        slots = max(1, min(self.concurrent_games, mine))
+        eng = SelfPlayLanes(self.game, evaluator, num_simulations=self.num_simulations, opening_book=int(book),
+                            lanes=self.lanes if self.lanes else (2 if slots >= 512 else 1),
+                             concurrent_games=slots, cpuct=self.cpuct,
                              dirichlet_alpha=self.dirichlet_alpha, dirichlet_epsilon=self.dirichlet_epsilon,
                              temperature_threshold=self.temperature_threshold, board_semantics=self.board_semantics,
                              reference_quirks=self.reference_quirks, seed=1000 + self.seed,   # key of the per-game streams: the same on every rank
