@@ -502,16 +502,16 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
         "metric": f"self-play positions/sec (+ MCTS node-expansions/sec) at {args.sims} sims, {args.rows}x{args.cols} board",
         "value": main_leg["positions"] / dt, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": args.scaling, "vs_baseline": None, "dtype": args.nn,
+        "scaling": getattr(args, "scaling", "weak"), "vs_baseline": None, "dtype": args.nn,
         "dtype_note": FP32_GRADE.get(args.nn, "reduced-precision evaluator (the reference evaluates in float32)"),
         "data": "synthetic",
         "expansions_per_s": main_leg["evals"] / dt, "simulations_per_s": main_leg["sims_total"] / dt,
         "config": {"workload": f"{args.rows}x{args.cols} board, {args.sims} sims/move, {args.games} concurrent games "
-                               f"{'per GPU' if args.scaling == 'weak' else 'in total (split over the ranks)'}, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
+                               f"{'per GPU' if getattr(args, 'scaling', 'weak') == 'weak' else 'in total (split over the ranks)'}, frozen random-init {args.channels}x{args.blocks} net (seed 0), "
                                f"{args.semantics} boards, reference_quirks={args.quirks}, staggered start plies",
                    "tree_arithmetic": "f32 PUCT + u64 bitboards", "nn_dtype": args.nn,
                    "evaluation_reuse": bool(main_leg.get("reuse", False)),
-                   "parallelism": f"episode-sharded x{world}", "lanes_per_gpu": args.lanes, "hipgraph": not args.no_graph},
+                   "parallelism": f"episode-sharded x{world}", "lanes_per_gpu": getattr(args, "lanes", 1), "hipgraph": not args.no_graph},
         "cpu_baseline": cpub, "gather_s": main_leg["gather_s"], "examples_gathered": main_leg["examples"],
         **roof, **(extra or {}),
     }

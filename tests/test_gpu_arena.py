@@ -453,3 +453,39 @@ def test_augmentation_and_example_format_on_device_tensors(tmp_path):
         q = T.TrainingDataQueue(max_size=100)
         q.push_file(ref_path, allow_reference_objects=True)
         assert len(q) == n
+
+
+def test_cli_train_mode_two_ranks(tmp_path):
+    """`train_alphazero.py --mode train` under the distributed launcher with two ranks (sharing this box's GPU, collectives over
+    gloo): one whole AlphaZero.run iteration -- self-play sharded over the ranks + ONE example exchange, the published file read by
+    both ranks, DistributedDataParallel training, the sharded arena match with its win counts all-reduced, promotion decided
+    once, checkpoints written by rank 0 behind barriers (ai/alphazero.py:249-270, ai/self_play.py:288-335).  Both ranks finish,
+    report ONE line, hold bit-identical weights after training, and leave exactly one set of files."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mdir, ddir = tmp_path / "models", tmp_path / "data"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "train_alphazero.py"), "--mode", "train", "--rows", "6", "--cols", "6",
+           "--iterations", "1", "--episodes", "12", "--simulations", "16", "--epochs", "2", "--batch-size", "16", "--channels", "32",
+           "--blocks", "1", "--arena-games", "6", "--concurrent-games", "8", "--model-dir", str(mdir), "--data-dir", str(ddir),
+           "--dist-backend", "gloo"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-5000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                            # rank 0 alone reports
+    it = json.loads(lines[0])["iterations"]
+    assert len(it) == 1
+    h = it[0]
+    assert os.path.exists(h["data_file"]) and h["examples"] > 0 and len(h["losses"]) == 2
+    assert len(h["param_checksums"]) == 2 and h["param_checksums"][0] == h["param_checksums"][1]      # DDP: identical weights on both ranks
+    assert h["arena"]["games"] == 6 and h["arena"]["a_wins"] + h["arena"]["b_wins"] + h["arena"]["draws"] == 6
+    assert abs(h["win_ratio"] - h["arena"]["a_wins"] / 6.0) < 1e-12 and h["promoted"] == (h["win_ratio"] >= 0.6)
+    z = np.load(h["data_file"])
+    assert sorted(set(z["game_id"].tolist())) == list(range(12))         # both ranks' games, gathered once
+    assert len(glob.glob(str(ddir / "self_play_data_*.npz"))) == 1 and not glob.glob(str(ddir / "*.tmp*"))
+    names = sorted(os.path.basename(f) for f in glob.glob(str(mdir / "*.pth.tar")))
+    assert names == ["best_model.pth.tar", "checkpoint_1.pth.tar", "current_model.pth.tar"]

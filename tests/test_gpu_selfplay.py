@@ -576,3 +576,46 @@ def test_lanes_play_the_same_games(pkg):
     moves = [lanes.play_move() for _ in range(2)] if False else None
     lanes.close()
     same(ref, got)
+
+
+@pytest.mark.parametrize("path", EPIS, ids=[os.path.basename(p) for p in EPIS])
+def test_batched_engine_replays_reference_transcripts_with_numpy_rng(pkg, path):
+    """SelfPlayEngine(rng="numpy"): every game of the batch draws from its own numpy RandomState(seed) exactly where the
+    reference's play_game draws from the global stream after np.random.seed(seed) (Dirichlet noise at the first search,
+    np.random.choice per move: ai/mcts.py:305, ai/self_play.py:146, 160).  All recorded reference games of one board
+    semantics are played TOGETHER in one lockstep batch (different lengths, per-game hash evaluators as recorded) and must
+    equal the G4 transcripts: the boards of the examples, pi and z, game by game."""
+    import torch
+    from hash_eval import hash_eval_batch, planes_to_boards
+    z = np.load(path)
+    R, C = z["search_boards"].shape[2:]
+    game = pkg.YinYangGame(R, C)
+    for copied in (0, 1):
+        games = np.flatnonzero(z["copied"] == copied)
+        pb, vb = z["pbits"][games], z["vbits"][games]
+
+        def ev(planes):                                   # slot g plays game games[g] for the whole run (no refill, no packing)
+            b = planes_to_boards(planes.cpu().numpy())
+            pol, val = np.zeros((len(games), R * C), np.float32), np.zeros(len(games), np.float32)
+            for key in set(zip(pb.tolist(), vb.tolist())):
+                idx = np.flatnonzero((pb == key[0]) & (vb == key[1]))
+                pol[idx], val[idx] = hash_eval_batch(b[idx], key[0], key[1])
+            return torch.from_numpy(pol).cuda(), torch.from_numpy(val).cuda()
+
+        sims = int(z["sims"][games[0]])
+        assert (z["sims"][games] == sims).all()
+        eng = pkg.SelfPlayEngine(game, ev, num_simulations=sims, concurrent_games=len(games), use_graph=False, compact_tail=False,
+                                 board_semantics="copied" if copied else "aliased", reference_quirks=True, rng="numpy",
+                                 numpy_seeds={g: int(z["seed"][games[g]]) for g in range(len(games))})
+        ex = eng.run(len(games))
+        eng.close()
+        gid, ply = ex["game_id"].cpu().numpy(), ex["ply"].cpu().numpy()
+        st, pi, zz = ex["states"].cpu().numpy(), ex["policies"].cpu().numpy(), ex["values"].cpu().numpy()
+        for g, i in enumerate(games):
+            n = int(z["n"][i])
+            sel = np.flatnonzero(gid == g)
+            sel = sel[np.argsort(ply[sel])]
+            assert len(sel) == n, (copied, i, len(sel), n)
+            assert np.array_equal(st[sel], z["example_boards"][i, :n]), (copied, i)
+            assert np.array_equal(pi[sel], z["pis"][i, :n].astype(np.float32)), (copied, i)
+            assert np.array_equal(zz[sel], z["z"][i, :n].astype(np.float32)), (copied, i)

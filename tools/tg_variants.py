@@ -6,7 +6,7 @@ import ctypes as ct, json, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-VARIANTS = {"base": [], "fullwin": ["-DTG_FULL_WINDOW"]}
+VARIANTS = {"base": [], "lofirst": ["-DTG_LO_FIRST"], "unrollkq": ["-DTG_UNROLL_KQ"], "both": ["-DTG_LO_FIRST", "-DTG_UNROLL_KQ"]}
 STUB = os.path.join(HERE, "tgv", "stub.cpp")
 
 

@@ -33,7 +33,12 @@ def parse_args(argv=None):
     p.add_argument("--mcts-threads", type=int, default=1)
     p.add_argument("--model-dir", type=str, default="models")
     p.add_argument("--data-dir", type=str, default="data")
-    p.add_argument("--resume", action="store_true")
+    p.add_argument("--resume", action="store_true",
+                   help="accepted for compatibility and inert, like the reference's (train_alphazero.py:55 parses it, nothing reads it): "
+                        "models and checkpoint_<n> files found in --model-dir are ALWAYS continued from (alphazero.py:66-73, "
+                        "training_pipeline.py:171-190); use --fresh to start over")
+    p.add_argument("--fresh", action="store_true",
+                   help="train: remove current_model / best_model / checkpoint_<n> from --model-dir first (start from a new random network)")
     p.add_argument("--mode", choices=["train", "self-play", "evaluate"], default="train")
     p.add_argument("--output-model", type=str, default="best_model.pth.tar")
     # engine flags
@@ -82,6 +87,15 @@ def main(argv=None):
     game = pkg.YinYangGame(args.rows, args.cols)
     for d in (args.model_dir, args.data_dir):
         os.makedirs(d, exist_ok=True)
+    if args.mode == "train" and args.fresh:
+        import glob
+        if rank == 0:
+            for f in glob.glob(os.path.join(args.model_dir, "checkpoint*.pth.tar")) + [os.path.join(args.model_dir, n) for n in
+                                                                                     ("current_model.pth.tar", "best_model.pth.tar")]:
+                if os.path.exists(f):
+                    os.remove(f)
+        if world > 1:
+            dist.barrier()
     if args.mode == "train":                     # train_alphazero.py:84-101
         az = pkg.AlphaZero(game, args.model_dir, args.data_dir, num_iterations=args.iterations, num_episodes=args.episodes,
                            num_simulations=args.simulations, num_epochs=args.epochs, num_workers=args.workers,
@@ -91,6 +105,8 @@ def main(argv=None):
         hist = az.run()
         if rank == 0:
             print(json.dumps({"iterations": hist}))
+        if world > 1:
+            dist.destroy_process_group()
         return
     model_path = os.path.join(args.model_dir, args.output_model)
     if args.mode == "evaluate":                  # train_alphazero.py:124-243: 10 games against RandomPlayer

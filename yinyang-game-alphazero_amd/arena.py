@@ -357,9 +357,16 @@ class AlphaZero:
             ratio = self.evaluate(self.current_model_path, self.best_model_path)
             t3 = time.perf_counter()
             promoted = self.update_best_model(ratio)
+            import torch.distributed as dist
+            sums = [run_training_pipeline.last["param_checksum"]]
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                every = [None] * dist.get_world_size()
+                dist.all_gather_object(every, sums[0])      # every rank's fingerprint of its weights after the DDP training
+                sums = every
             self.history.append(dict(iteration=it + 1, data_file=data_file, self_play_s=t1 - t0, train_s=t2 - t1,
                                      arena_s=t3 - t2, win_ratio=ratio, promoted=promoted, arena=self.last_arena,
-                                     losses=run_training_pipeline.last["metrics"]["total_loss"]))
+                                     losses=run_training_pipeline.last["metrics"]["total_loss"],
+                                     examples=run_training_pipeline.last["examples"], param_checksums=sums))
         return self.history
 
 

@@ -371,9 +371,14 @@ class OpeningBook:
         player, keys, states = 1, [], []
         for _ in range(self.max_stones):                       # breadth-first over stone counts; a side without a move ends a line
             players = torch.full((boards.shape[0],), player, dtype=torch.int8, device=dev)
-            bi, a = valid_mask(boards, players, rowcol).nonzero(as_tuple=True)
-            if bi.numel() == 0:
+            vm = valid_mask(boards, players, rowcol)
+            n_children = int(vm.sum())                          # before de-duplication: what the expansion below allocates
+            if n_children == 0:
                 break
+            if n_children > 8 * max_positions:                  # a frontier this wide cannot fit the budget: stop BEFORE expanding it
+                self.max_stones = len(keys)
+                break
+            bi, a = vm.nonzero(as_tuple=True)
             child = boards.reshape(-1, self.A)[bi]
             child[torch.arange(bi.numel(), device=dev), a] = player
             black, white = pack_boards(child.view(-1, R, C))
@@ -552,6 +557,18 @@ class BatchedMCTS:
         self.book = book
         self.book_version = getattr(self, "book_version", 0) + 1      # captured steps hold the table's pointers: LockstepSearch re-captures
 
+    def bind_evaluator(self, evaluator):
+        """Evaluations kept across searches (keep_evaluations) and the opening book are results of ONE network: the first search
+        binds the context to its evaluator; a search with another one clears the cache and drops the book instead of silently
+        mixing two networks' numbers."""
+        owner = getattr(self, "_evaluator_owner", None)
+        if owner is not None and owner is not evaluator:
+            if self.keep_evaluations:
+                self.clear_evaluation_cache()
+            if getattr(self, "book", None) is not None:
+                self.set_book(None)
+        self._evaluator_owner = evaluator
+
     def clear_evaluation_cache(self):
         with torch.cuda.device(self.device):
             check(lib().yy_mcts_cache_clear(self._h, _stream()))
@@ -567,6 +584,7 @@ class BatchedMCTS:
         simulation) and returns the root visit counts int32 [G,A]."""
         if num_sims > self.max_sims:
             raise _lib.YYError(-1, f"num_sims {num_sims} > max_sims {self.max_sims} the context was sized for")
+        self.bind_evaluator(evaluator)
         self.begin(boards, root_players, active)
         policy, _ = evaluator(self.planes)
         self.expand_root(policy, noise, eps)

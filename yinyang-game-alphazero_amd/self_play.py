@@ -91,6 +91,7 @@ class LockstepSearch:
             self.graphs.clear()
             self._book_version = getattr(ctx, "book_version", 0)
         rows = ctx.G if rows is None else min(int(rows), ctx.G)
+        ctx.bind_evaluator(self.evaluator)                     # kept evaluations / the book belong to ONE network
         ctx.begin(boards, root_players, active)
         policy, _ = self._evaluate(rows)                       # mcts.py:295, value discarded
         ctx.expand_root(policy, noise, eps)
@@ -126,7 +127,7 @@ class SelfPlayEngine:
                  board_semantics="copied", reference_quirks=False, use_graph=True, seed=0,
                  device=None, first_game_index=0, game_index_stride=1, compact_tail=True, row_tiers=None,
                  reuse_pass_value=None, reuse_transpositions=None, keep_evaluations=None,
-                 opening_book=None, stream=None):
+                 opening_book=None, stream=None, rng="philox", numpy_seeds=None):
         """reuse_pass_value / reuse_transpositions / keep_evaluations: None = on when the boards are copied and the evaluator
         declares `row_independent` (the split-f16 evaluator does).  The reference asks the network for every leaf: a node
         without legal moves again on every visit (ai/mcts.py:93-95, 371-397), a position another move order of the same search
@@ -137,7 +138,13 @@ class SelfPlayEngine:
         lifetime, which is what keep_evaluations needs.
         opening_book: an engine.OpeningBook built with THIS evaluator, or a stone count N to build one here (every position
         reachable with <= N stones is evaluated once, in large batches, before play; all games start from the empty board, so
-        the first plies of every game search the same positions), or None."""
+        the first plies of every game search the same positions), or None.
+        rng: "philox" (default) = the per-game counter streams of csrc/yy_selfplay.hip, drawn on the device; "numpy" = the
+        REFERENCE's generator and call sequence, per game: a host numpy RandomState(numpy_seeds[game index], default seed +
+        index) draws np.random.dirichlet at the game's first search (ai/mcts.py:305) and np.random.choice for every move
+        (ai/self_play.py:146, 160) exactly where SelfPlayWorker.play_game draws from the global stream after np.random.seed(s) --
+        a batch of games then replays the reference's transcripts move for move (tests: episodes_*.npz).  One host round
+        trip of (pi, legal mask) per move: a parity mode, not the throughput path."""
         assert board_semantics in ("aliased", "copied")
         self.game = game
         self.R, self.C = game.getBoardSize()
@@ -172,6 +179,8 @@ class SelfPlayEngine:
             self.ctx.set_book(opening_book)
         self.search = LockstepSearch(self.ctx, evaluator, use_graph=use_graph)
         self.seed = int(seed)                      # key of the per-game counter streams (csrc/yy_selfplay.hip)
+        assert rng in ("philox", "numpy")
+        self.rng, self.numpy_seeds, self._rs = rng, numpy_seeds, {}
         self.n_alive = 0                           # live games, tracked on the host (no device read needed)
         self.first_game_index, self.stride = int(first_game_index), int(game_index_stride)
         # a game has at most A placements; passes never add examples.  Literal quirk mode can make
@@ -251,6 +260,39 @@ class SelfPlayEngine:
         self._start_games(idx[:room])
 
     # ---- one lockstep move for every live game (self_play.py:91-192)
+    # ---- rng="numpy": the reference's generator, one RandomState per game
+    def _numpy_stream(self, gid):
+        rs = self._rs.get(gid)
+        if rs is None:
+            seed = self.seed + gid if self.numpy_seeds is None else int(self.numpy_seeds[gid])
+            rs = self._rs[gid] = np.random.RandomState(seed)
+        return rs
+
+    def _numpy_actions(self, searching, pi, mask_u8):
+        """self_play.py:143-160 on the host, game by game, from each game's own RandomState."""
+        idx = searching.nonzero(as_tuple=True)[0]
+        action = torch.full((self.G,), -1, dtype=torch.int32, device=self.device)
+        if idx.numel() == 0:
+            return action
+        pi_h, m_h = pi[idx].cpu().numpy(), mask_u8[idx].cpu().numpy().astype(np.float64)
+        gid_h, ply_h = self.game_id[idx].cpu().numpy(), self.ply[idx].cpu().numpy()
+        out = np.zeros(len(gid_h), np.int32)
+        for j, gid in enumerate(gid_h):
+            rs, p, valid = self._numpy_stream(int(gid)), pi_h[j], m_h[j]
+            if ply_h[j] >= self.thr:                                           # temperature 0: random among the most visited
+                out[j] = rs.choice(np.where(p == np.max(p))[0])
+            else:
+                probs = p * valid
+                if np.sum(probs) > 0:
+                    probs = probs / np.sum(probs)
+                else:
+                    vi = np.flatnonzero(valid)
+                    probs = np.zeros_like(valid)
+                    probs[vi] = 1.0 / len(vi)
+                out[j] = rs.choice(len(probs), p=probs)
+        action[idx] = torch.from_numpy(out).to(self.device)
+        return action
+
     def _on_stream(self):
         import contextlib
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
@@ -320,7 +362,17 @@ class SelfPlayEngine:
         mask_u8 = engine.valid_mask(self.boards, rp, self.rowcol)
         s_u8 = searching.to(torch.uint8)
         noise = None
-        if self.eps > 0:                                                       # add_noise = (step == 0), :131
+        if self.eps > 0 and self.rng == "numpy":                               # the reference's own draw, game by game (mcts.py:298-312)
+            first = (searching & (self.ply == 0)).nonzero(as_tuple=True)[0]
+            noise = torch.zeros((G, self.A), dtype=torch.float64, device=dev)
+            if first.numel():
+                m_host, gid_host = mask_u8[first].cpu().numpy(), self.game_id[first].cpu().numpy()
+                rows = np.zeros((len(gid_host), self.A), np.float64)
+                for j, gid in enumerate(gid_host):
+                    idx = np.flatnonzero(m_host[j])
+                    rows[j, idx] = self._numpy_stream(int(gid)).dirichlet([self.alpha] * len(idx))
+                noise[first] = torch.from_numpy(rows).to(dev)
+        elif self.eps > 0:                                                     # add_noise = (step == 0), :131
             first = (searching & (self.ply == 0)).to(torch.uint8)
             noise = engine.root_noise(self.seed, self.game_id, self.ply, first, mask_u8, self.alpha)
         self.search.run(self.boards, rp, self.sims, noise=noise, eps=self.eps, active=s_u8, rows=self.rows)
@@ -332,7 +384,10 @@ class SelfPlayEngine:
         self.hist_player[ar, slot] = torch.where(searching, self.players, self.hist_player[ar, slot])
         self.n_ex += searching.to(torch.int64)
         # ---- choose the action (:143-160) from the game's own stream
-        action = engine.sample_actions(self.seed, self.game_id, self.ply, s_u8, pi, mask_u8, self.thr)
+        if self.rng == "numpy":
+            action = self._numpy_actions(searching, pi, mask_u8)
+        else:
+            action = engine.sample_actions(self.seed, self.game_id, self.ply, s_u8, pi, mask_u8, self.thr)
         # ---- make the move (:163); aliased: the search has mutated the game's board (Q2)
         if self.aliased:
             self.boards = torch.where(searching[:, None, None], self.ctx.boards(), self.boards)
@@ -368,6 +423,8 @@ class SelfPlayEngine:
         while self.n_alive > 0:
             self.play_move()
             moves += 1
+            if moves % 8 == 0:
+                self.ctx.status()    # a failed search (NaN from the evaluator, arena overflow) stops the run now, not at its end
             if progress and moves % 10 == 0:
                 progress(self)
         self.ctx.status()            # per-game search errors are sticky on the device: any failure of any move raises here
@@ -479,6 +536,8 @@ class SelfPlayLanes:
                 else:
                     live.remove(l)
             moves += 1
+            if moves % 8 == 0:
+                self.ctx.status()    # a failed search (NaN from the evaluator, arena overflow) stops the run now, not at its end
             if progress and moves % 10 == 0:
                 progress(self)
         self.ctx.status()            # per-game search errors are sticky on the device: any failure of any move raises here
@@ -566,21 +625,28 @@ def publish_examples_file(ex, output_dir, reference_format=False):
     rank = dist.get_rank() if multi else 0
     os.makedirs(output_dir, exist_ok=True)
     filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}.npz")
+    n = 1
+    while os.path.exists(filename):                    # two publications within one second: never overwrite
+        filename = os.path.join(output_dir, f"self_play_data_{int(time.time())}_{n}.npz")
+        n += 1
     if multi:
         names = [filename]
         dist.broadcast_object_list(names, src=0)
         filename = names[0]
     if rank == 0:
-        tmp = f"{filename}.{os.getpid()}.tmp.npz"
+        # temporary name that the loaders' glob (self_play_data_*.npz) cannot match: a crash before the rename leaves no
+        # half-written file that would be picked up as training data
+        tmp = f"{filename}.{os.getpid()}.partial"
         states = ex["states"].cpu().numpy()
-        if reference_format:
-            # `boards` = pickled board objects of the reference's own class, readable by ITS TrainingDataQueue.push_file
-            from .training import save_examples_reference_format
-            save_examples_reference_format(tmp, states, ex["policies"].cpu().numpy(), ex["values"].cpu().numpy())
-        else:
-            np.savez(tmp, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
-                     values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),
-                     ply=ex["ply"].cpu().numpy())
+        with open(tmp, "wb") as fh:
+            if reference_format:
+                # `boards` = pickled board objects of the reference's own class, readable by ITS TrainingDataQueue.push_file
+                from .training import save_examples_reference_format
+                save_examples_reference_format(fh, states, ex["policies"].cpu().numpy(), ex["values"].cpu().numpy())
+            else:
+                np.savez(fh, boards=states, states=states, policies=ex["policies"].cpu().numpy().astype(np.float64),
+                         values=ex["values"].cpu().numpy().astype(np.float64), game_id=ex["game_id"].cpu().numpy(),
+                         ply=ex["ply"].cpu().numpy())
         os.replace(tmp, filename)
     if multi:
         dist.barrier()

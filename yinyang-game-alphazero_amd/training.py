@@ -504,7 +504,11 @@ def run_training_pipeline(game, model_dir="models", data_dir="data", num_iterati
     pipe.load_data()
     t0 = time.perf_counter()
     metrics = pipe.train(num_iterations)
-    run_training_pipeline.last = dict(metrics=metrics, seconds=time.perf_counter() - t0, examples=len(pipe.data_queue))
+    with torch.no_grad():       # fingerprint of THIS rank's weights after training (data-parallel ranks must agree bit for bit)
+        ps = [p.detach().double() for p in pipe.trainer.nnet.parameters()]
+        checksum = [float(sum(p.sum() for p in ps)), float(sum(p.abs().sum() for p in ps))]
+    run_training_pipeline.last = dict(metrics=metrics, seconds=time.perf_counter() - t0, examples=len(pipe.data_queue),
+                                      param_checksum=checksum)
     if not os.path.exists(pipe.get_latest_model_path()):
         pipe.trainer.save_checkpoint(iteration=pipe.iteration if pipe.iteration > 0 else None)
     return pipe.get_latest_model_path()
