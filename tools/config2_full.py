@@ -8,7 +8,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import yinyang_game_alphazero_amd as pkg
-from yinyang_game_alphazero_amd.self_play import SelfPlayEngine
+from yinyang_game_alphazero_amd.self_play import SelfPlayLanes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--games", type=int, default=4096)
@@ -19,29 +19,31 @@ ap.add_argument("--rows", type=int, default=8)
 ap.add_argument("--single", action="store_true", help="only the plain run (no 2x refilled run)")
 ap.add_argument("--reuse", type=int, default=1, help="1 = the engine's evaluation reuse (its default); 0 = the evaluator gets every row the reference evaluates")
 ap.add_argument("--book", type=int, default=0, help="shared opening book: positions with at most this many stones (0 = none)")
+ap.add_argument("--lanes", type=int, default=2, help="HIP streams the slots are cut over (self_play.SelfPlayLanes)")
+ap.add_argument("--cols", type=int, default=0)
 ap.add_argument("--out", default="gpurun_out/config2_full.json")
 a = ap.parse_args()
 torch.manual_seed(0)
-game = pkg.YinYangGame(a.rows, a.rows)
+game = pkg.YinYangGame(a.rows, a.cols or a.rows)
 net = pkg.YinYangNeuralNetwork(game).cuda().eval()
 ev = pkg.BatchedEvaluator(net, a.nn)
 res = []
 for total in ((a.games,) if a.single else (a.games, 2 * a.games)):
     kw = {} if a.reuse else dict(reuse_pass_value=False, reuse_transpositions=False, keep_evaluations=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()          # the book's build time is inside the wall time
-    eng = SelfPlayEngine(game, ev, num_simulations=a.sims, concurrent_games=a.slots, seed=1000, opening_book=a.book, **kw)
+    eng = SelfPlayLanes(game, ev, num_simulations=a.sims, concurrent_games=a.slots, lanes=a.lanes, seed=1000, opening_book=a.book, **kw)
     last = [t0]
 
     def progress(e):
         if time.perf_counter() - last[0] > 30:
             last[0] = time.perf_counter()
-            print("[config2] %d games, %.0f s, %d slots alive" % (total, last[0] - t0, int(e.alive.sum())), flush=True)
+            print("[config2] %d games, %.0f s, %d slots alive" % (total, last[0] - t0, e.n_alive), flush=True)
     ex = eng.run(total, progress=progress)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     c = eng.ctx.status()
     n = int(ex["values"].shape[0])
     plies = torch.bincount(ex["game_id"] - ex["game_id"].min()).float()
-    r = dict(board=f"{a.rows}x{a.rows}", games=total, slots=a.slots, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
+    r = dict(board=f"{a.rows}x{a.cols or a.rows}", games=total, slots=a.slots, lanes=a.lanes, sims=a.sims, nn=a.nn, wall_s=dt, positions=n, positions_per_s=n / dt,
              evaluation_reuse=bool(a.reuse), opening_book_stones=a.book, book_positions=(eng.book.n if eng.book is not None else 0), evaluator_rows=int(c["evals"]), evaluator_rows_per_s=c["evals"] / dt,
              pass_values_reused=int(c["reused_values"]), cache_hits=int(c["transposition_hits"]),
              simulations_per_s=n * a.sims / dt, plies_mean=float(plies.mean()),

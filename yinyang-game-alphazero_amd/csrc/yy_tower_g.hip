@@ -123,21 +123,12 @@ __device__ __forceinline__ uint32_t tap_addr(int nb, int crs, const LaneGeo<GEO>
 // nb % P; right after its MFMAs the slot is refilled with the block P further down the (tap, block) stream, so a fragment is
 // read P - 1 blocks (>= 190 cycles of MFMA time) before its use and only 8 * P registers hold activations.
 template <int NB> struct XWin {
-#ifdef TG_FULL_WINDOW
-    static constexpr int P = NB;
-#else
     static constexpr int P = (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : NB;
-#endif
     f16x8 h[P], l[P];
 };
 template <class GEO> __device__ __forceinline__ void load_x1(XWin<GEO::NB> &f, int slot, const unsigned char *lds, uint32_t cb) {
-#ifdef TG_LO_FIRST      // lo requested first: the block's first MFMA (which needs hi) then waits for both with ONE s_waitcnt
-    f.l[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(lds + cb + GEO::PART_BYTES));
-    f.h[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(lds + cb));
-#else
     f.h[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(lds + cb));
     f.l[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(lds + cb + GEO::PART_BYTES));
-#endif
 }
 // acc1 += w_hi * x_hi ;  acc2 += w_lo * x_hi + w_hi * x_lo for the two M blocks of one column block (6 MFMAs).  Two
 // accumulators because every MFMA rounds its accumulator once: the large sum is rounded once per k-step (as in an f32 dot
@@ -200,18 +191,8 @@ __device__ __forceinline__ void run_layer(f32x4 (&acc1)[GEO::NB][2], f32x4 (&acc
         step(std::integral_constant<int, 8>{}, std::false_type{}, cur, nxt);
     };
     taps(std::true_type{}, lds, lds + 64);                                 // channel group 0, peeled: no zero / non-zero branch
-#ifdef TG_UNROLL_KQ       // every channel group its own code: the group's offset becomes the ds_read immediate (no v_add per read)
-    // (sched_barrier: one scheduling region per group -- the sched_group_barrier pipeline solver is exponential in region size)
-    __builtin_amdgcn_sched_barrier(0);
-    if (KQ > 1) taps(std::false_type{}, lds + 64, lds + 128);
-    __builtin_amdgcn_sched_barrier(0);
-    if (KQ > 2) taps(std::false_type{}, lds + 128, lds + 192);
-    __builtin_amdgcn_sched_barrier(0);
-    if (KQ > 3) taps(std::false_type{}, lds + 192, lds + 256);
-#else
 #pragma unroll 1
     for (int kq = 1; kq < KQ; kq++) taps(std::false_type{}, lds + kq * 64, lds + (kq + 1) * 64);
-#endif
 }
 
 template <int NW_, int NB_, int D_>

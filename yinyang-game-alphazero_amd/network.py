@@ -447,6 +447,7 @@ class BatchedEvaluator:
                 self.h3_exps = (kw_r, kh_r, ACT_EXP)
                 self.use_h3r = True
                 self.mode = mode = "f16x3"
+            self._hint = {}                      # owner token -> live rows of that owner's last compacted launch (rows_hint())
             self.supports_compaction = True      # __call__(planes, needs_eval=...) evaluates only the flagged rows
             self.supports_static = True          # __call__(..., static=True): results in buffers kept per batch size
             self._static = {}
@@ -503,6 +504,20 @@ class BatchedEvaluator:
                 self.fc2_w = net.value_fc2.weight.detach().float().reshape(-1).contiguous()
                 self.fc2_b = net.value_fc2.bias.detach().float().reshape(1).contiguous()
                 self.n_actions = A
+
+    def form_key(self, owner):
+        """Which tower form(s) a compacted call of this owner would enqueue now: part of the key of a captured step."""
+        hint = getattr(self, "_hint", {}).get(owner)
+        if hint is None or not hasattr(self, "g_split"):
+            return 0
+        return 1 if hint >= 2 * self.g_split else 0
+
+    def rows_hint(self, owner, G):
+        """Read (one small device read; call it where the host waits anyway) how many rows `owner`'s last compacted launch at
+        batch size G evaluated, and remember it as the hint for that owner's next launches."""
+        buf = getattr(self, "_static", {}).get((G, owner))
+        if buf is not None:
+            self._hint[owner] = int(buf[1].item())
 
     def _fold(self):
         n, dt = self.net, self.dtype
@@ -565,9 +580,16 @@ class BatchedEvaluator:
                     feats = tg(self.g_big, (-1, 0x7FFFFFFF), feats)
                 elif G <= self.g_split:
                     feats = tg(self.g_small, (-1, 0x7FFFFFFF), feats)
-                else:       # the live row count is only known on the device: both forms are enqueued, the gate picks one (same bits)
-                    feats = tg(self.g_small, (-1, self.g_split), feats)
-                    feats = tg(self.g_big, (self.g_split, 0x7FFFFFFF), feats)
+                else:
+                    # the live row count is only known on the device: both forms are enqueued, the gate picks one (same bits) --
+                    # unless the owner's last launch was far above the split (rows_hint): then only the large form (an unneeded
+                    # launch is not free: its empty workgroups queue behind the other lane's running ones)
+                    hint = self._hint.get(static) if static is not True and static is not False else None
+                    if hint is not None and hint >= 2 * self.g_split:
+                        feats = tg(self.g_big, (-1, 0x7FFFFFFF), feats)
+                    else:       # (a small count at the END of a search says little about its first steps: never small-only)
+                        feats = tg(self.g_small, (-1, self.g_split), feats)
+                        feats = tg(self.g_big, (self.g_split, 0x7FFFFFFF), feats)
             logits, hidden = engine.fc_heads(feats, self.fc_w, self.fc_b, self.fc_jobs, self.n_actions, self.n_hidden, self.fc_exps, n,
                                              logits, hidden)
             return engine.head_finish_f32(logits, hidden, self.fc2_w, self.fc2_b, rows, n, pol, val)

@@ -98,7 +98,8 @@ class LockstepSearch:
         ctx.select()
         done = 0
         n_fused = num_sims - 1
-        graph = self.graphs.get(rows)
+        gkey = rows if not hasattr(self.evaluator, "form_key") else (rows, self.evaluator.form_key(id(self)))
+        graph = self.graphs.get(gkey)
         if self.use_graph and graph is None and n_fused > self.eager_sims:
             for _ in range(self.eager_sims):                   # warm-up (MIOpen algo search etc.) = real sims
                 self._sim_step(rows)
@@ -107,7 +108,7 @@ class LockstepSearch:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._sim_step(rows)
-            self.graphs[rows] = graph
+            self.graphs[gkey] = graph
         if not self.use_graph:
             graph = None
         while done < n_fused:
@@ -309,6 +310,8 @@ class SelfPlayEngine:
         host, event, fin, fin_res, fin_player = self._pending
         self._pending = None
         event.synchronize()
+        if hasattr(self.evaluator, "rows_hint"):           # the stream is idle here: how many rows did the last step evaluate?
+            self.evaluator.rows_hint(id(self.search), self.rows if self.rows < self.G else self.G)
         n_pos, n_fin = int(host[0]), int(host[1])
         self.positions += n_pos
         if n_fin:
