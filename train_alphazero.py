@@ -5,8 +5,9 @@
     python train_alphazero.py --mode self-play --rows 8 --cols 8 --simulations 800 --episodes 4096
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_alphazero.py --mode self-play ...
 
-Flags added to the reference's set: --concurrent-games, --board-semantics {copied,aliased},
---reference-quirks, --nn {bf16,fp32}, --seed, --arena-games, --channels, --blocks.  `--mode train` runs
+Flags added to the reference's set: --concurrent-games, --lanes, --board-semantics {copied,aliased}, --reference-quirks,
+--nn {auto,f16x3,bf16,fp32,fp32t}, --evaluation-reuse, --opening-book-stones, --seed, --arena-games, --channels, --blocks, --fresh,
+--dist-backend, --reference-format.  `--mode train` runs
 the iteration loop (GPU self-play -> PyTorch-ROCm training -> batched arena -> promote at 0.6) and
 `--mode evaluate` plays 10 games against RandomPlayer, like the reference's modes.
 """
@@ -60,6 +61,9 @@ def parse_args(argv=None):
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="collectives of a multi-rank launch: nccl = RCCL over xGMI (one rank per GPU); gloo = over the host, "
                         "which also allows several ranks to share one GPU (rehearsals on a 1-GPU box)")
+    p.add_argument("--lanes", type=int, default=0,
+                   help="self-play: HIP streams the rank's concurrent games are cut over (0 = automatic: 2 from 512 games on); a lane's "
+                        "evaluator launch fills the compute units the other lane's last round of workgroups leaves idle; same games")
     p.add_argument("--arena-games", type=int, default=40)
     p.add_argument("--channels", type=int, default=128)
     p.add_argument("--blocks", type=int, default=10)
@@ -125,7 +129,7 @@ def main(argv=None):
                                        num_channels=args.channels, num_res_blocks=args.blocks,
                                        reference_format=args.reference_format,
                                        evaluation_reuse=None if args.evaluation_reuse == "auto" else False,
-                                       opening_book_stones=args.opening_book_stones)
+                                       opening_book_stones=args.opening_book_stones, lanes=args.lanes or None)
     if rank == 0:
         st = pkg.generate_self_play_data.last_stats
         st = dict(st, positions_per_s=st["positions"] / st["seconds"], expansions_per_s=st["evals"] / st["seconds"])
