@@ -558,9 +558,10 @@ class BatchedMCTS:
         self.book_version = getattr(self, "book_version", 0) + 1      # captured steps hold the table's pointers: LockstepSearch re-captures
 
     def bind_evaluator(self, evaluator):
-        """Evaluations kept across searches (keep_evaluations) and the opening book are results of ONE network: the first search
-        binds the context to its evaluator; a search with another one clears the cache and drops the book instead of silently
-        mixing two networks' numbers."""
+        """Evaluations kept across searches (keep_evaluations) and the opening book are results of ONE network: the engine-level
+        searches (self_play.LockstepSearch: SelfPlayEngine, MCTS, Arena) bind the context to their evaluator object; a search with
+        another one clears the cache and drops the book instead of silently mixing two networks' numbers.  The low-level
+        search() below takes any callable per call and does not bind: there clear_evaluation_cache() is the caller's job."""
         owner = getattr(self, "_evaluator_owner", None)
         if owner is not None and owner is not evaluator:
             if self.keep_evaluations:
@@ -584,7 +585,6 @@ class BatchedMCTS:
         simulation) and returns the root visit counts int32 [G,A]."""
         if num_sims > self.max_sims:
             raise _lib.YYError(-1, f"num_sims {num_sims} > max_sims {self.max_sims} the context was sized for")
-        self.bind_evaluator(evaluator)
         self.begin(boards, root_players, active)
         policy, _ = evaluator(self.planes)
         self.expand_root(policy, noise, eps)
