@@ -619,3 +619,63 @@ def test_batched_engine_replays_reference_transcripts_with_numpy_rng(pkg, path):
             assert np.array_equal(st[sel], z["example_boards"][i, :n]), (copied, i)
             assert np.array_equal(pi[sel], z["pis"][i, :n].astype(np.float32)), (copied, i)
             assert np.array_equal(zz[sel], z["z"][i, :n].astype(np.float32)), (copied, i)
+
+
+def test_evaluation_reuse_across_the_drain_tiers_plays_the_same_games(pkg):
+    """1 100 games through 1 024 slots with the live split-f16 evaluator (128 channels): the batch refills, then drains through
+    the row tiers (1 024 -> 512 -> 256: packed live games, one captured step per tier, tower forms chosen on the device), and the
+    evaluation cache + a shared opening book feed results computed in one batch size into searches running at another.  Every
+    state, pi, z of every game is bit-identical with the reuse on and off, on one lane and on two -- the property that the
+    evaluator's rows do not depend on the batch (tests/test_gpu_network.py) seen from the engine."""
+    import torch
+    game = pkg.YinYangGame(6, 6)
+    torch.manual_seed(0)
+    ev = pkg.BatchedEvaluator(pkg.YinYangNeuralNetwork(game, 128, 1).cuda().eval())
+    assert ev.mode == "f16x3" and ev.row_independent
+
+    def play(reuse, lanes, book):
+        eng = pkg.SelfPlayLanes(game, ev, num_simulations=16, concurrent_games=1024, lanes=lanes, seed=21, opening_book=book,
+                                reuse_pass_value=reuse, reuse_transpositions=reuse, keep_evaluations=reuse)
+        assert any(t < 1024 // lanes for t in eng.lanes[0].tiers)
+        ex = eng.run(1100)
+        c = eng.ctx.status()
+        eng.close()
+        order = torch.argsort(ex["game_id"] * 1000 + ex["ply"])
+        return {k: v[order].cpu() for k, v in ex.items()}, c
+
+    ref, c_off = play(False, 1, None)
+    assert sorted(set(ref["game_id"].tolist())) == list(range(1100))
+    for lanes, book in ((1, 3), (2, 3)):
+        got, c_on = play(None, lanes, book)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (lanes, k)
+        assert c_on["evals"] < c_off["evals"] and c_on["transposition_hits"] > 0
+
+
+def test_changing_the_evaluator_clears_kept_evaluations_and_drops_the_book(pkg):
+    """Evaluations kept across searches and the opening book are results of ONE network.  An engine that is handed another
+    evaluator (search.evaluator = ...) must not serve the old network's numbers: the context is bound to the evaluator object,
+    a search with a different one clears the cache and drops the book -- the games it then plays equal a fresh engine's."""
+    import torch
+    game = pkg.YinYangGame(6, 6)
+    evs = []
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        evs.append(pkg.BatchedEvaluator(pkg.YinYangNeuralNetwork(game, 32, 1).cuda().eval()))
+    eng = pkg.SelfPlayEngine(game, evs[0], num_simulations=16, concurrent_games=32, seed=3, opening_book=2)
+    assert eng.keep_evaluations and eng.ctx.book is not None
+    eng.run(32)                                                  # fills the cache with network 0's evaluations
+    eng.evaluator = eng.search.evaluator = evs[1]
+    ex = eng.run(32)                                             # games 32..63 with network 1
+    assert eng.ctx.book is None
+    eng.close()
+    fresh = pkg.SelfPlayEngine(game, evs[1], num_simulations=16, concurrent_games=32, seed=3, first_game_index=32)
+    want = fresh.run(32)
+    fresh.close()
+    for e in (ex, want):
+        order = torch.argsort(e["game_id"] * 1000 + e["ply"])
+        for k in e:
+            e[k] = e[k][order].cpu()
+    assert sorted(set(ex["game_id"].tolist())) == list(range(32, 64))
+    for k in want:
+        assert torch.equal(ex[k], want[k]), k

@@ -353,3 +353,19 @@ def test_bench_multi_rank_control_flow_gloo_world2(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert abs(line["value"] - 75 / (line["ms_per_step"] * 5 / 1e3)) < 1e-6 * line["value"]
     assert "10 sims" in line["metric"] and "4x4" in line["metric"] and line["vs_baseline"] is None
+
+
+def test_publish_examples_file_name_is_unique_and_leaves_no_partial(tmp_path):
+    """Two publications within one second get two files (no overwrite); the temporary name does not match the loaders' glob."""
+    import glob
+    import torch
+    from yinyang_game_alphazero_amd.self_play import publish_examples_file
+    ex = dict(states=torch.zeros((3, 4, 4), dtype=torch.int8), policies=torch.full((3, 16), 1.0 / 16), values=torch.zeros(3),
+              game_id=torch.arange(3), ply=torch.zeros(3, dtype=torch.int64))
+    a = publish_examples_file(ex, str(tmp_path))
+    b = publish_examples_file(ex, str(tmp_path))
+    assert a != b and os.path.exists(a) and os.path.exists(b)
+    assert sorted(glob.glob(str(tmp_path / "self_play_data_*.npz"))) == sorted([a, b])
+    assert not glob.glob(str(tmp_path / "*.partial"))
+    z = np.load(a)
+    assert z["states"].shape == (3, 4, 4) and z["policies"].dtype == np.float64

@@ -43,6 +43,7 @@ class LockstepSearch:
         self.timer = None      # optional object with start()/stop() bracketing every tree-kernel launch (bench.py)
         self._policy = self._value = None
         self._book_version = getattr(ctx, "book_version", 0)
+        self._graph_evaluator = evaluator
 
     @property
     def graph(self):
@@ -87,11 +88,13 @@ class LockstepSearch:
         """rows: evaluate only leaf rows [0, rows) -- the caller guarantees every active game has an index below it
         (SelfPlayEngine packs the live games to the front when a batch drains).  One graph per distinct `rows`."""
         ctx = self.ctx
-        if getattr(ctx, "book_version", 0) != self._book_version:       # kernel arguments of a captured step are frozen: the book changed
+        ctx.bind_evaluator(self.evaluator)                     # kept evaluations / the book belong to ONE network (may drop the book)
+        if getattr(ctx, "book_version", 0) != self._book_version or self._graph_evaluator is not self.evaluator:
+            # a captured step has its kernel arguments frozen (the book's tables) and calls the evaluator it was captured with
             self.graphs.clear()
             self._book_version = getattr(ctx, "book_version", 0)
+            self._graph_evaluator = self.evaluator
         rows = ctx.G if rows is None else min(int(rows), ctx.G)
-        ctx.bind_evaluator(self.evaluator)                     # kept evaluations / the book belong to ONE network
         ctx.begin(boards, root_players, active)
         policy, _ = self._evaluate(rows)                       # mcts.py:295, value discarded
         ctx.expand_root(policy, noise, eps)
