@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2,
                     help="HIP streams the rank's games are cut over (self_play.SelfPlayLanes): one lane's evaluator launch fills the "
                          "compute units the other lane's partly empty last round of workgroups leaves idle; 1 = one lockstep batch")
+    ap.add_argument("--split-wg", type=int, default=0,
+                    help="experiment: live-row count (in small-form workgroups) up to which a compacted evaluator launch takes the "
+                         "one-board tower form (network.G_SPLIT_WG; 0 = the shipped value)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -519,6 +522,9 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
 
 def main():
     args = parse()
+    if args.split_wg > 0:          # (how network.G_SPLIT_WG was chosen)
+        from yinyang_game_alphazero_amd import network as _net
+        _net.G_SPLIT_WG = args.split_wg
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return

@@ -416,7 +416,7 @@ def test_split_f16_every_kernel_form_writes_the_same_bits(R, C, ch):
 
 def test_split_f16_form_chosen_on_the_device_writes_the_same_bits():
     """BatchedEvaluator with compaction on a mid-size batch: both kernel forms of the tower are enqueued, gated on the device-side
-    live row count (<= 320 rows: one 8x8 board per workgroup, more: two).  For row counts on both sides of the split, at it,
+    live row count (<= g_split rows: one 8x8 board per workgroup, more: two).  For row counts on both sides of the split, at it,
     zero and the whole batch: the evaluator returns what the dense evaluation returns, bit for bit, and the gated launches
     write exactly the rows below the count."""
     import torch
@@ -425,20 +425,21 @@ def test_split_f16_form_chosen_on_the_device_writes_the_same_bits():
     torch.manual_seed(0)
     net = pkg.YinYangNeuralNetwork(pkg.YinYangGame(8, 8)).cuda().eval()
     ev = pkg.BatchedEvaluator(net, "f16x3")
-    assert ev.g_small == (4, 1) and ev.g_big == (8, 2) and ev.g_split == 320
+    assert ev.g_small == (4, 1) and ev.g_big == (8, 2)
+    S = ev.g_split
     G = 1024
     rng = np.random.default_rng(4)
     planes = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(G, 8, 8)).astype(np.int8)).cuda())
     dense_p, dense_v = ev(planes)
     dense_f = E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 8, 2, ev.g_hw, ev.g_hb)
-    for n_live in (0, 1, 7, 319, 320, 321, 600, 1024):
+    for n_live in (0, 1, 7, S - 1, S, S + 1, (S + G) // 2, 1024):
         flags = torch.zeros(G, dtype=torch.uint8, device="cuda")
         flags[torch.from_numpy(rng.choice(G, n_live, replace=False)).cuda()] = 1
         rows, n = E.compact_rows(flags)
         assert int(n) == n_live
         got = torch.full((G, 2, 2048), -7.0, device="cuda")
-        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 4, 1, ev.g_hw, ev.g_hb, rows, n, got, (-1, 320))
-        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 8, 2, ev.g_hw, ev.g_hb, rows, n, got, (320, 0x7FFFFFFF))
+        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 4, 1, ev.g_hw, ev.g_hb, rows, n, got, (-1, S))
+        E.tower_g(planes, ev.g_w, ev.g_b, ev.h3_layers, ev.g_exps, 8, 2, ev.g_hw, ev.g_hb, rows, n, got, (S, 0x7FFFFFFF))
         assert torch.equal(got[:n_live], dense_f[rows[:n_live].long()]), n_live
         assert n_live == G or bool((got[n_live:] == -7.0).all())
         p, v = ev(planes, needs_eval=flags)
@@ -465,7 +466,7 @@ def test_evaluator_rows_do_not_depend_on_the_batch(R):
     base = E.encode_planes(torch.from_numpy(rng.integers(-1, 2, size=(B, R, R)).astype(np.int8)).cuda())
     p_ref, v_ref = (t.clone() for t in ev(base))
     assert bool(torch.isfinite(p_ref).all()) and bool(torch.isfinite(v_ref).all())
-    for M in (1, 96, 256, 320, 321, 1024, 3072, 3928, 4096, 8192):
+    for M in (1, 96, 256, 320, 321, 512, 513, 1024, 3072, 3928, 4096, 8192):
         idx = torch.from_numpy(rng.integers(0, B, size=M)).cuda() if M > 1 else torch.tensor([77], device="cuda")
         planes = base[idx].contiguous()
         p, v = ev(planes)
