@@ -13,8 +13,8 @@
 // Numerics as in the tower (yy_tower_g.hip): x = hi + lo float16 pairs (22 significant bits), weights times 2^kw, features
 // times 2^ka, acc1 += w_hi*x_hi, acc2 += w_lo*x_hi + w_hi*x_lo, out = (acc1 + acc2) * 2^-(kw+ka) + bias.
 //
-// Work split: job = (tile of 64 dense rows, slice of <= 64 outputs of one head); wave w = outputs [16w, 16w+16) of the slice x
-// the 64 rows (four 16-column blocks).  Features f32 [row][head][K] are staged through LDS in chunks of 128 k, split into
+// Work split: job = (tile of 64 -- 32 for batches of at most 2048 rows -- dense rows, slice of <= 64 outputs of one head);
+// wave w = outputs [16w, 16w+16) of the slice x the tile's rows (16-row blocks).  Features f32 [row][head][K] are staged through LDS in chunks of 128 k, split into
 // hi / lo on the way (rows of 256 B at a stride of 288 B: conflict-free for this MFMA's B-operand reads), double buffered,
 // one barrier per chunk; the weights of a slice ([k-step][wave][part][lane][8 f16], network.pack_fc_heads) go global ->
 // register in MFMA operand order, one chunk (four k-steps) ahead.
@@ -35,7 +35,7 @@ extern "C" int yy_tower_set_err(int code, const char *msg);
 
 namespace fch {
 
-constexpr int ROWS = 64, KC = 128, RS = 288, PART_BYTES = ROWS * RS, STAGE_BYTES = 2 * PART_BYTES;
+constexpr int KC = 128, RS = 288;
 
 __device__ __forceinline__ void split_pair(const f32x2 a, uint32_t &hi, uint32_t &lo) {
     const f16x2 h = __builtin_convertvector(a, f16x2);
@@ -49,10 +49,12 @@ struct Job {
     int head, out0, nout, wchunk;      // wchunk: first 8 KB k-step block of the slice's weights
 };
 
+template <int ROWS>      // dense rows per tile: 64, or 32 for small batches (twice the workgroups, half the feature bytes per workgroup)
 __global__ void __launch_bounds__(256, 2)
 k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wpk, const float *__restrict__ bias,
            const Job *__restrict__ jobs, int n_jobs, float *__restrict__ logits, float *__restrict__ hidden,
            const int *__restrict__ n_rows, int G, int K, int A, int H, float in_scale, float out_scale) {
+    constexpr int PART_BYTES = ROWS * RS, STAGE_BYTES = 2 * PART_BYTES, NBR = ROWS / 16, NI = ROWS / 8;
     __shared__ __attribute__((aligned(256))) unsigned char lds[2 * STAGE_BYTES];
     const int n_live = n_rows ? min(*n_rows, G) : G;
     const int tile = blockIdx.x / n_jobs, jb = blockIdx.x - tile * n_jobs;
@@ -64,22 +66,22 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
     const int n_chunks = (K + KC - 1) / KC;
     const bool active = wave * 16 < job.nout;                // a wave past the slice's outputs only helps staging
 
-    // staging: thread t moves float4 #(t % 32) of rows t/32 + 8*i (i = 0..7) of the chunk
+    // staging: thread t moves float4 #(t % 32) of rows t/32 + 8*i (i = 0 .. ROWS/8 - 1) of the chunk
     const int sq = threadIdx.x & 31, sr = threadIdx.x >> 5;
-    auto stage_load = [&](f32x4 (&fr)[8], int c) {
+    auto stage_load = [&](f32x4 (&fr)[NI], int c) {
         const int k = c * KC + sq * 4;
         const int kc = k < K ? k : 0;                                             // unconditional loads (no branch between the
         const float km = k < K ? 1.0f : 0.0f;                                     // prefetches); k >= K contributes zeros
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NI; i++) {
             const int row = min(r0 + sr + 8 * i, n_live - 1);                    // rows past the live count repeat the last one (never stored)
             fr[i] = *(const f32x4 *)(feats + ((size_t)row * 2 + job.head) * K + kc) * km;
         }
     };
-    auto stage_store = [&](const f32x4 (&fr)[8], int s) {
+    auto stage_store = [&](const f32x4 (&fr)[NI], int s) {
         unsigned char *base = lds + s * STAGE_BYTES + sq * 8;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < NI; i++) {
             const f32x4 v = fr[i] * in_scale;
             uint32_t h01, l01, h23, l23;
             split_pair((f32x2){v[0], v[1]}, h01, l01);
@@ -89,9 +91,9 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
         }
     };
     const unsigned char *wbase = wpk + ((size_t)job.wchunk * 4 + wave) * 2048 + lane * 16;   // + ks * 8192; hi, lo 1 KB apart
-    f32x4 acc1[4], acc2[4];
+    f32x4 acc1[NBR], acc2[NBR];
 #pragma unroll
-    for (int nb = 0; nb < 4; nb++) acc1[nb] = acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NBR; nb++) acc1[nb] = acc2[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // this wave's weight fragments of one chunk: [k-step 4]{hi, lo}; loaded a whole chunk (768 MFMA cycles) ahead
     auto load_wc = [&](f16x8 (&w)[KC / 32][2], int c) {
@@ -107,10 +109,10 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
     auto compute = [&](const f16x8 (&w)[KC / 32][2], int stage) {
         if (!active) return;
         const unsigned char *xs = lds + stage * STAGE_BYTES + n16 * RS + kg * 16;
-        constexpr int NG = (KC / 32) * 4, P = 4;
+        constexpr int NG = (KC / 32) * NBR, P = 4;
         f16x8 xh[P], xl[P];
         auto rd = [&](int g, int slot) {
-            const int ks = g >> 2, nb = g & 3;
+            const int ks = g / NBR, nb = g % NBR;
             xh[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + nb * 16 * RS + ks * 64));
             xl[slot] = __builtin_bit_cast(f16x8, *(const u32x4 *)(xs + PART_BYTES + nb * 16 * RS + ks * 64));
         };
@@ -119,7 +121,7 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * P, 0);      // the window's first fill stays in front of the first MFMA
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            const int ks = g >> 2, nb = g & 3, slot = g % P;
+            const int ks = g / NBR, nb = g % NBR, slot = g % P;
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][1], xh[slot], acc2[nb], 0, 0, 0);
             acc1[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][0], xh[slot], acc1[nb], 0, 0, 0);
             acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks][0], xl[slot], a, 0, 0, 0);
@@ -133,7 +135,7 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
     // the feature tensor was just written by the tower launch and comes from the Infinity Cache / HBM.  Chunk indices past
     // the end are clamped (they re-read the last chunk; never stored, never multiplied).
     const int last = n_chunks - 1;
-    f32x4 f0[8], f1[8];                      // f0: the odd chunk after the one computing, f1: the even chunk after that
+    f32x4 f0[NI], f1[NI];                    // f0: the odd chunk after the one computing, f1: the even chunk after that
     f16x8 w0[KC / 32][2], w1[KC / 32][2];    // w0: weights of the even chunk computing / to come, w1: of the odd one
     stage_load(f1, 0);
     load_wc(w0, 0);
@@ -164,7 +166,7 @@ k_fc_heads(const float *__restrict__ feats, const unsigned char *__restrict__ wp
 #pragma unroll
     for (int i = 0; i < 4; i++) b[i] = (o0 + i < job.out0 + job.nout) ? bias[boff + o0 + i] : 0.0f;
 #pragma unroll
-    for (int nb = 0; nb < 4; nb++) {
+    for (int nb = 0; nb < NBR; nb++) {
         const int row = r0 + nb * 16 + n16;
         if (row < n_live) {
 #pragma unroll
@@ -186,10 +188,15 @@ extern "C" int yy_nn_fc_heads_f16x3(const float *feats, const void *wpk, const f
     if (G == 0) return YY_OK;
     if (!feats || !wpk || !bias || !jobs || !logits || !hidden || G < 0 || n_jobs < 1 || K < 32 || (K & 31) || A < 1 || H < 1)
         return yy_tower_set_err(YY_E_INVALID, "yy_nn_fc_heads_f16x3: bad argument");
-    const int tiles = (G + fch::ROWS - 1) / fch::ROWS;
-    fch::k_fc_heads<<<dim3(tiles * n_jobs), dim3(256), 0, (hipStream_t)s>>>(feats, (const unsigned char *)wpk, bias, (const fch::Job *)jobs,
-                                                                           n_jobs, logits, hidden, n_rows, G, K, A, H,
-                                                                           ldexpf(1.0f, act_exp), ldexpf(1.0f, -(weight_exp + act_exp)));
+    // tiles of 32 rows for batches up to 2048 rows (a lane of the engine), 64 above: the same bits either way (one fixed
+    // k-ascending chain per output), only the work split differs
+    const float in_scale = ldexpf(1.0f, act_exp), out_scale = ldexpf(1.0f, -(weight_exp + act_exp));
+    if (G <= 2048)
+        fch::k_fc_heads<32><<<dim3(((G + 31) / 32) * n_jobs), dim3(256), 0, (hipStream_t)s>>>(
+            feats, (const unsigned char *)wpk, bias, (const fch::Job *)jobs, n_jobs, logits, hidden, n_rows, G, K, A, H, in_scale, out_scale);
+    else
+        fch::k_fc_heads<64><<<dim3(((G + 63) / 64) * n_jobs), dim3(256), 0, (hipStream_t)s>>>(
+            feats, (const unsigned char *)wpk, bias, (const fch::Job *)jobs, n_jobs, logits, hidden, n_rows, G, K, A, H, in_scale, out_scale);
     if (hipGetLastError() != hipSuccess) return yy_tower_set_err(YY_E_HIP, "yy_nn_fc_heads_f16x3: launch failed");
     return YY_OK;
 }
