@@ -297,8 +297,9 @@ def test_bench_json_contract(tmp_path):
     assert ru["opening_book"]["positions"] == ru["opening_book"]["stored"] == 769880 and ru["opening_book"]["build_s"] > 0
 
 
-@pytest.mark.parametrize("nproc,backend", [(2, "gloo"), (1, "nccl")], ids=["2 ranks on one GPU, gloo", "1 rank, RCCL"])
-def test_bench_under_the_distributed_launcher(nproc, backend):
+@pytest.mark.parametrize("nproc,backend,scaling", [(2, "gloo", "weak"), (2, "gloo", "strong"), (1, "nccl", "weak")],
+                         ids=["2 ranks on one GPU, gloo", "2 ranks, gloo, strong scaling", "1 rank, RCCL"])
+def test_bench_under_the_distributed_launcher(nproc, backend, scaling):
     """The command the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
     with the REAL engine: two ranks sharing this box's one GPU (collectives over gloo: RCCL refuses two ranks on one device), and
     one rank with the RCCL communicator (the example exchange is then a real RCCL all_gather_into_tensor on device buffers).
@@ -310,18 +311,19 @@ def test_bench_under_the_distributed_launcher(nproc, backend):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(29611 + nproc), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-           "--games", "320", "--sims", "24", "--dist-backend", backend, "--no-cpu-baseline"]
+           "--games", "320", "--sims", "24", "--dist-backend", backend, "--no-cpu-baseline", "--scaling", scaling]
+    per_rank = 320 if scaling == "weak" else 320 // nproc      # strong: --games in total, split over the ranks
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == nproc and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f16x3"
+    assert d["n_gpus"] == nproc and d["steps"] == 2 and d["scaling"] == scaling and d["dtype"] == "f16x3"
     if nproc > 1:                                              # the CPU leg and the extra legs are N = 1 only
         assert d["cpu_baseline"] is None and "secondary" not in d and "with_evaluation_reuse" not in d
     assert f"episode-sharded x{nproc}" == d["config"]["parallelism"]
     # staggered starts: some slots are between games in a given move, most are searching
-    assert 0.5 * 2 * 320 * nproc <= d["value"] * d["ms_per_step"] * 2 / 1e3 <= 2 * 320 * nproc
+    assert 0.5 * 2 * per_rank * nproc <= d["value"] * d["ms_per_step"] * 2 / 1e3 <= 2 * per_rank * nproc
     assert d["examples_gathered"] > 0 and d["gather_s"] >= 0
 
 
