@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--split-wg", type=int, default=0,
                     help="experiment: live-row count (in small-form workgroups) up to which a compacted evaluator launch takes the "
                          "one-board tower form (network.G_SPLIT_WG; 0 = the shipped value)")
+    ap.add_argument("--no-form-hint", action="store_true",
+                    help="experiment: never tell the evaluator the rows per step (it then enqueues both tower forms, device-gated)")
     ap.add_argument("--semantics", default="copied", choices=["copied", "aliased"])
     ap.add_argument("--quirks", action="store_true", help="reference_quirks (Q4/Q5)")
     ap.add_argument("--no-graph", action="store_true")
@@ -522,6 +524,9 @@ def result_line(args, main_leg, world, extra=None, cpub=None):
 
 def main():
     args = parse()
+    if args.no_form_hint:
+        from yinyang_game_alphazero_amd import network as _net
+        _net.BatchedEvaluator.rows_hint = lambda self, owner, mean_rows: None
     if args.split_wg > 0:          # (how network.G_SPLIT_WG was chosen)
         from yinyang_game_alphazero_amd import network as _net
         _net.G_SPLIT_WG = args.split_wg

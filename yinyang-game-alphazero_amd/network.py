@@ -514,12 +514,11 @@ class BatchedEvaluator:
             return 0
         return 1 if hint >= 2 * self.g_split else 0
 
-    def rows_hint(self, owner, G):
-        """Read (one small device read; call it where the host waits anyway) how many rows `owner`'s last compacted launch at
-        batch size G evaluated, and remember it as the hint for that owner's next launches."""
-        buf = getattr(self, "_static", {}).get((G, owner))
-        if buf is not None:
-            self._hint[owner] = int(buf[1].item())
+    def rows_hint(self, owner, mean_rows):
+        """Tell the evaluator how many rows per step `owner`'s last move evaluated on average (the engine knows it from the tree
+        context's counters where it waits for the move anyway): decides the tower form of that owner's next launches."""
+        if hasattr(self, "_hint"):
+            self._hint[owner] = float(mean_rows)
 
     def _fold(self):
         n, dt = self.net, self.dtype
@@ -583,13 +582,16 @@ class BatchedEvaluator:
                 elif G <= self.g_split:
                     feats = tg(self.g_small, (-1, 0x7FFFFFFF), feats)
                 else:
-                    # the live row count is only known on the device: both forms are enqueued, the gate picks one (same bits) --
-                    # unless the owner's last launch was far above the split (rows_hint): then only the large form (an unneeded
-                    # launch is not free: its empty workgroups queue behind the other lane's running ones)
+                    # The live row count is only known on the device: both forms are enqueued, each gated on it (same bits either
+                    # way; the count swings widely between the steps of one search, and picking per step beats picking one form
+                    # per move: 6 146 against 5 342 positions/s on the evaluation-reuse leg, bench.py --no-form-hint).  Only when
+                    # the owner's last move averaged far more rows per step than the split (rows_hint) is the small form's launch
+                    # dropped: an unneeded gated launch is not free under lanes, its empty workgroups queue behind the other
+                    # lane's running ones.
                     hint = self._hint.get(static) if static is not True and static is not False else None
                     if hint is not None and hint >= 2 * self.g_split:
                         feats = tg(self.g_big, (-1, 0x7FFFFFFF), feats)
-                    else:       # (a small count at the END of a search says little about its first steps: never small-only)
+                    else:
                         feats = tg(self.g_small, (-1, self.g_split), feats)
                         feats = tg(self.g_big, (self.g_split, 0x7FFFFFFF), feats)
             logits, hidden = engine.fc_heads(feats, self.fc_w, self.fc_b, self.fc_jobs, self.n_actions, self.n_hidden, self.fc_exps, n,

@@ -164,6 +164,7 @@ class SelfPlayEngine:
         self.evaluator = evaluator
         self.stream = stream                       # HIP stream every launch of this engine goes to (None: the caller's current one)
         self._pending = None                       # a move enqueued by enqueue_move() and not yet finished
+        self._evals_seen = 0                       # tree-context counter at the end of the last move (rows_hint)
         if reuse_pass_value is None:
             reuse_pass_value = (not self.aliased) and bool(getattr(evaluator, "row_independent", False))
         if reuse_transpositions is None:
@@ -313,8 +314,12 @@ class SelfPlayEngine:
         host, event, fin, fin_res, fin_player = self._pending
         self._pending = None
         event.synchronize()
-        if hasattr(self.evaluator, "rows_hint"):           # the stream is idle here: how many rows did the last step evaluate?
-            self.evaluator.rows_hint(id(self.search), self.rows if self.rows < self.G else self.G)
+        if hasattr(self.evaluator, "rows_hint"):
+            # the stream is idle here: rows the evaluator was asked for per step of this move (also surfaces a failed search now)
+            evals = self.ctx.status()["evals"]
+            if evals >= self._evals_seen:
+                self.evaluator.rows_hint(id(self.search), (evals - self._evals_seen) / float(self.sims + 1))
+            self._evals_seen = evals
         n_pos, n_fin = int(host[0]), int(host[1])
         self.positions += n_pos
         if n_fin:
