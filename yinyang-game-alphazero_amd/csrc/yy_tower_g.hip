@@ -177,6 +177,9 @@ __device__ __forceinline__ void run_layer(f32x4 (&acc1)[GEO::NB][2], f32x4 (&acc
         // refill the ring entry just consumed (the tail of the stream re-reads the last chunk: uniform vmcnt)
         load_w(W[S], weights + (size_t)min(chunk + D, n_tower - 1) * GEO::CHUNK_BYTES, voff);
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);     // the four fragment loads stay here, behind this chunk's MFMAs
+        // one scheduling region per chunk: the sched_group_barrier solver is superlinear in region size -- with the nine chunks of a
+        // channel group in one region this file took 8 minutes to compile, with this line 20 seconds; same kernel time
+        __builtin_amdgcn_sched_barrier(0);
         chunk++;
     };
     auto taps = [&](auto zt, const unsigned char *cur, const unsigned char *nxt) {

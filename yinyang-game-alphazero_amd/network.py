@@ -584,7 +584,8 @@ class BatchedEvaluator:
                 else:
                     # The live row count is only known on the device: both forms are enqueued, each gated on it (same bits either
                     # way; the count swings widely between the steps of one search, and picking per step beats picking one form
-                    # per move: 6 146 against 5 342 positions/s on the evaluation-reuse leg, bench.py --no-form-hint).  Only when
+                    # per move: 6 146 against 5 342 positions/s on the evaluation-reuse leg; ONE launch holding both forms was
+                    # built and measured too: no gain over the two gated launches, 6 104 against 6 107).  Only when
                     # the owner's last move averaged far more rows per step than the split (rows_hint) is the small form's launch
                     # dropped: an unneeded gated launch is not free under lanes, its empty workgroups queue behind the other
                     # lane's running ones.
