@@ -273,6 +273,15 @@ def roofline_pass(eng):
                 tl[0](rows, n_rows)
                 tt.stop()
             live = (tt.mean_ms()[0], int(n_rows.item()))
+            if len(lanes) > 1:      # ... and on ONE lane's compacted rows: the launch a kernel trace of the timed steps lists
+                tl1 = tower_launcher(eng, lane.ctx.planes)
+                rows1, n1 = E.compact_rows(lane.ctx.needs_eval)
+                tt = HipEventTimer(reps)
+                for _ in range(reps):
+                    tt.start()
+                    tl1[0](rows1, n1)
+                    tt.stop()
+                live = live + (tt.mean_ms()[0], int(n1.item()))
     return k_ms, n, counters, e0.elapsed_time(e1) / reps, move_ms, tower_ms, live, lane.G, planes
 
 
@@ -480,11 +489,17 @@ def make_roofline(args, eng, games):
                             "timed": "20 launches on every row of the live leaf batch, hipEventRecord on the launch stream"},
                "roofline_tree_kernel": roof_tree}
         if live is not None:      # what the lockstep step launches (and what a rocprofv3 summary of this command averages over)
-            lms, lrows = live
+            lms, lrows = live[:2]
             lach = flops / games * lrows / (lms * 1e-3) / 1e12
             out["roofline"].update(live_rows=lrows, live_launch_ms=lms, live_achieved=lach, live_frac=lach / peak,
-                                   live_note="the same kernel on the compacted rows of one pending leaf batch (rows that need an "
-                                             "evaluation): the launch of the timed steps; fewer whole rounds of workgroups than the dense launch")
+                                   live_note="the same kernel on the compacted rows of the pending leaf batch of all lanes (rows that "
+                                             "need an evaluation); fewer whole rounds of workgroups than the dense launch")
+            if len(live) == 4:
+                out["roofline"].update(lane_live_rows=live[3], lane_live_launch_ms=live[2],
+                                       lane_live_achieved=flops / games * live[3] / (live[2] * 1e-3) / 1e12,
+                                       lane_note="ONE lane's compacted launch alone on the chip: what the timed steps enqueue (two lanes, "
+                                                 "two streams); in a kernel trace of the bench command its duration is longer, because "
+                                                 "the two lanes' launches overlap and share the compute units")
     Cc = args.channels
     flops_leaf = (2 * 9 * 5 * Cc * A + 2 * args.blocks * (2 * 9 * Cc * Cc * A) + 2 * (2 * Cc * 32 * A)
                   + 2 * 32 * A * A + 2 * 32 * A * 256 + 512)
