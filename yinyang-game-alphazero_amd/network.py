@@ -380,7 +380,12 @@ def reference_precision_mode(net):
 
 def f16x3_covers(net):
     """True where the split-f16 kernels (csrc/yy_tower_g.hip + yy_fc_heads.hip) cover the network: any board of at most 144 cells,
-    32 / 64 / 96 / 128 channels, at most 10 residual blocks, 32-channel head convolutions."""
+    32 / 64 / 96 / 128 channels, at most 10 residual blocks, 32-channel head convolutions.
+    Range: activations live times 2^ACT_EXP in float16 pairs, so an activation (or head feature) above 65504 / 2^ACT_EXP = 8188
+    becomes inf, then NaN; the tree kernel turns a NaN prior / value into the game's sticky error flag and the engine raises at
+    the end of that MOVE (SelfPlayEngine.finish_move reads the context's status once per move).  Networks of this architecture
+    (BatchNorm after every convolution) stay orders of magnitude below it: the largest activation over the round's soaks was
+    ~10; a network that does not should be evaluated with mode "fp32"."""
     R, C = net.board_size
     return (R * C <= G_MAX_CELLS and net.conv1.out_channels in G_CHANNELS and len(net.res_blocks) <= 10
             and net.policy_conv.out_channels == HEAD_CHANNELS and net.value_conv.out_channels == HEAD_CHANNELS)
