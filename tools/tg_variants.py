@@ -6,7 +6,10 @@ import ctypes as ct, json, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-VARIANTS = {"base": [], "lofirst": ["-DTG_LO_FIRST"], "unrollkq": ["-DTG_UNROLL_KQ"], "both": ["-DTG_LO_FIRST", "-DTG_UNROLL_KQ"]}
+# name -> extra hipcc flags; add an entry per experiment macro placed in csrc/yy_tower_g.hip (the round-3 experiments -- full fragment
+# window, lo-before-hi reads, unrolled channel groups, ring depth 3, epilogue fused into a block-major last group, one dual-form
+# launch -- were built this way, measured against "base" in one process and removed again: DESIGN.md section 3)
+VARIANTS = {"base": []}
 STUB = os.path.join(HERE, "tgv", "stub.cpp")
 
 

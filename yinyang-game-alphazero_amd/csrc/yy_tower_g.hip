@@ -119,11 +119,12 @@ __device__ __forceinline__ uint32_t tap_addr(int nb, int crs, const LaneGeo<GEO>
     return (g.okmask[nb] & (1u << TAP)) ? a : ((a & 255u) | (uint32_t)GEO::ZERO_OFF);
 }
 
-// Activation fragments: a rotating window of P column blocks ({hi, lo} x 4 registers each).  Block nb of a chunk lives in slot
-// nb % P; right after its MFMAs the slot is refilled with the block P further down the (tap, block) stream, so a fragment is
-// read P - 1 blocks (>= 190 cycles of MFMA time) before its use and only 8 * P registers hold activations.
+// Activation fragments of one chunk ({hi, lo} x 4 registers per column block), refreshed IN PLACE: right after the MFMAs of block
+// nb its slot takes the NEXT chunk's fragment of block nb, i.e. a fragment is requested a whole chunk (6 * NB MFMAs) before its use
+// and 8 * NB registers hold activations.  (A shorter rotating window of 3-4 blocks -- 24-32 registers -- was the first form of this
+// kernel; with one scheduling region per chunk the full window measures 1.8 % faster at NB = 8 and still fits at NB = 9.)
 template <int NB> struct XWin {
-    static constexpr int P = (NB % 4 == 0) ? 4 : (NB % 3 == 0) ? 3 : NB;
+    static constexpr int P = NB;
     f16x8 h[P], l[P];
 };
 template <class GEO> __device__ __forceinline__ void load_x1(XWin<GEO::NB> &f, int slot, const unsigned char *lds, uint32_t cb) {
