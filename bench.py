@@ -385,9 +385,10 @@ def timed_region(eng, steps, warmup, rank, world, dist, cdev, sims, capacity=Non
     eng.ctx.reset_counters()
     barrier()
     t0 = time.perf_counter()
-    positions = 0
+    positions, marks = 0, [t0]
     for _ in range(steps):
         positions += eng.play_move()
+        marks.append(time.perf_counter())           # a move ends with the lanes' host reads: wall time per step, no extra sync
     barrier()
     dt = time.perf_counter() - t0
     counters = eng.ctx.status()
@@ -407,7 +408,8 @@ def timed_region(eng, steps, warmup, rank, world, dist, cdev, sims, capacity=Non
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dt = float(mx[2])
     return dict(games=eng.G, steps=steps, dt=dt, positions=float(tot[0]), evals=float(tot[1]), served=float(tot[3]), gather_s=gather_s,
-                examples=int(ex_all["states"].shape[0]), sims_total=steps * sims * eng.G * world,
+                examples=int(ex_all["states"].shape[0]), sims_total=steps * sims * eng.G * world, warmup=warmup,
+                step_ms=[round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])],
                 eval_fraction=counters["evals"] / max(steps * sims * eng.G, 1))
 
 
@@ -511,7 +513,8 @@ def make_roofline(args, eng, games):
 def leg_summary(leg, note):
     return {"nn": leg["nn"], "games_per_gpu": leg["games"], "steps": leg["steps"], "value": leg["positions"] / leg["dt"],
             "unit": "positions/s", "expansions_per_s": leg["evals"] / leg["dt"], "simulations_per_s": leg["sims_total"] / leg["dt"],
-            "ms_per_step": leg["dt"] / leg["steps"] * 1e3, "eval_fraction": leg["eval_fraction"], "note": note}
+            "ms_per_step": leg["dt"] / leg["steps"] * 1e3, "eval_fraction": leg["eval_fraction"],
+            "warmup": leg.get("warmup"), "step_ms": leg.get("step_ms"), "note": note}
 
 
 def result_line(args, main_leg, world, extra=None, cpub=None):
@@ -591,12 +594,15 @@ def main():
                 ": REDUCED precision against the reference's float32 (not the headline; parity figures in "
                 "tests/test_gpu_mcts.py::test_live_gpu_evaluator_search_vs_reference_pi)"))
         if args.reuse_steps > 0 and not args.reuse_evaluations and args.semantics == "copied":
-            leg = run_leg(args, args.nn, args.games, args.reuse_steps, 1, rank, world, dist, cdev, False, reuse=True)
+            leg = run_leg(args, args.nn, args.games, args.reuse_steps, max(1, args.warmup), rank, world, dist, cdev, False, reuse=True)
             s = leg_summary(leg, "same workload and evaluator with the engine's evaluation reuse ON (the SelfPlayEngine default for this "
                                  "evaluator; OFF in the headline so that the evaluator sees the reference's rows one for one): a node "
                                  "without legal moves is evaluated once instead of on every visit (ai/mcts.py:93-95), and a leaf whose "
                                  "position this search or an earlier search of the same game has evaluated takes the cached policy row "
-                                 "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games)")
+                                 "and value (:385-397); the games are the same move for move (tests/test_gpu_selfplay.py::test_evaluation_reuse_plays_the_same_games). "
+                                 "The games enter at staggered plies with EMPTY evaluation caches, which fill during the first moves: the leg takes "
+                                 "the main leg's W untimed warm-up moves, step_ms lists the timed moves one by one, and the whole-run figure with "
+                                 "every transient inside (book build, cold caches, the draining tail) is profiles/r03_config2_full_run_evaluation_reuse_book.json")
             s["evaluator_rows_per_s"] = s.pop("expansions_per_s")      # rows really evaluated
             s["opening_book"] = leg.get("book")
             if leg.get("book"):
