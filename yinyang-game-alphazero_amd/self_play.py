@@ -36,9 +36,12 @@ class LockstepSearch:
     the capture stream (the C ABI takes the stream as an argument), so a replay costs one host call
     instead of ~60 kernel launches."""
 
-    def __init__(self, ctx, evaluator, use_graph=True, eager_sims=3):
+    def __init__(self, ctx, evaluator, use_graph=True, eager_sims=3, unroll=None):
         self.ctx, self.evaluator, self.use_graph = ctx, evaluator, use_graph
         self.eager_sims = eager_sims
+        # simulations per replayed graph: besides the one-step graph a second one holds `unroll` consecutive steps
+        # (fewer host calls, and no graph-to-graph launch gap between the steps inside it); 1 = one-step graphs only
+        self.unroll = max(1, int(os.environ.get("YY_GRAPH_UNROLL", "8") if unroll is None else unroll))
         self.graphs = {}       # evaluated rows -> captured step
         self.timer = None      # optional object with start()/stop() bracketing every tree-kernel launch (bench.py)
         self._policy = self._value = None
@@ -112,9 +115,20 @@ class LockstepSearch:
             with torch.cuda.graph(graph):
                 self._sim_step(rows)
             self.graphs[gkey] = graph
+            if self.unroll > 1 and n_fused - done >= 2 * self.unroll:
+                many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(many):
+                    for _ in range(self.unroll):
+                        self._sim_step(rows)
+                self.graphs[(gkey, self.unroll)] = many
+        many = self.graphs.get((gkey, self.unroll)) if self.use_graph else None
         if not self.use_graph:
             graph = None
         while done < n_fused:
+            if many is not None and n_fused - done >= self.unroll:
+                many.replay()
+                done += self.unroll
+                continue
             if graph is not None:
                 graph.replay()
             else:
