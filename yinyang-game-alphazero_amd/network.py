@@ -19,9 +19,12 @@ import torch.nn.functional as F
 H3_BOARDS = ((6, 6), (8, 8), (12, 12))      # board shapes the 32x32x16 split-f16 kernels cover (csrc/yy_tower_h3r.hip: A/B partner of the general kernel)
 G_MAX_CELLS = 144                # the general split-f16 tower (csrc/yy_tower_g.hip): any R x C board up to this many cells
 G_CHANNELS = (32, 64, 96, 128)   # ... and these widths
-G_SPLIT_WG = 512                 # live rows <= this many workgroups of the small form: the small form runs, else the large one.  Measured with
-                                 # two lanes (bench.py --split-wg, one box, evaluation-reuse leg at 4096 games = ~400 live rows per lane
-                                 # launch): 320 -> 5 580 positions/s, 448 / 512 -> 6 145-6 265, 640 -> 6 150, 768 -> 5 930; no effect at 8 192 games
+G_SPLIT_WG = 256                 # live rows <= this many workgroups of the small form (= ONE round of workgroups on the 256 CUs): the small
+                                 # form runs, else the large one.  One launch alone on the chip (tools/tower_rows_sweep.py, 8x8): one-board form
+                                 # 209 us up to 256 rows, 415 up to 512; two-board form 347 us up to 512 rows.  With two lanes on the
+                                 # evaluation-reuse leg at 4096 games (bench.py --split-wg, one box; rows per launch rise from ~12 to ~800 inside a
+                                 # search, tools/reuse_rows_hist.py): 192 -> 6 781 positions/s, 256 -> 7 118, 320 -> 7 073, 384 -> 7 054,
+                                 # 512 -> 6 990, 640 -> 6 846
 G_AUTO_MAX_WG = 2048             # batches up to this many small-form workgroups enqueue both forms, gated on the device-side row count
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
