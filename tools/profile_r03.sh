@@ -9,7 +9,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --secondary-nn none --reuse-steps 0 > "$O/bench_stats_run.json" 2> "$O/bench_stats_run.err" || exit 1
 echo "bench stats done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_reuse" -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --secondary-nn none --reuse-steps 0 --reuse-evaluations 1 > "$O/bench_reuse_stats_run.json" 2> "$O/bench_reuse_stats_run.err" || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_reuse" -- python3 "$R/bench.py" --steps 6 --warmup 4 --no-cpu-baseline --secondary-nn none --reuse-steps 0 --reuse-evaluations 1 > "$O/bench_reuse_stats_run.json" 2> "$O/bench_reuse_stats_run.err" || exit 1
 echo "reuse stats done"
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
     timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex "k_mcts" --output-format csv -d "$O/pmc_mcts_$pass" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-graph --no-cpu-baseline --secondary-nn none --reuse-steps 0 > "$O/pmc_mcts_$pass.log" 2>&1 || exit 1
