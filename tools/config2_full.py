@@ -22,7 +22,17 @@ ap.add_argument("--book", type=int, default=0, help="shared opening book: positi
 ap.add_argument("--lanes", type=int, default=2, help="HIP streams the slots are cut over (self_play.SelfPlayLanes)")
 ap.add_argument("--cols", type=int, default=0)
 ap.add_argument("--out", default="gpurun_out/config2_full.json")
+ap.add_argument("--split-wg", type=int, default=0, help="override network.G_SPLIT_WG (A/B)")
+ap.add_argument("--form", default="auto", choices=["auto", "big"], help="big = the evaluator always launches the large tower form only (A/B)")
+ap.add_argument("--free-running", action="store_true", help="each lane's next move is enqueued as soon as its last one was read back, instead of all lanes starting every move together as SelfPlayLanes.run() does (A/B: how run() was decided)")
 a = ap.parse_args()
+if a.form == "big":
+    from yinyang_game_alphazero_amd import network as _net
+    _real_hint = _net.BatchedEvaluator.rows_hint
+    _net.BatchedEvaluator.rows_hint = lambda self, owner, mean_rows: _real_hint(self, owner, 1e9)
+if a.split_wg:
+    from yinyang_game_alphazero_amd import network as _net
+    _net.G_SPLIT_WG = a.split_wg
 torch.manual_seed(0)
 game = pkg.YinYangGame(a.rows, a.cols or a.rows)
 net = pkg.YinYangNeuralNetwork(game).cuda().eval()
@@ -38,7 +48,25 @@ for total in ((a.games,) if a.single else (a.games, 2 * a.games)):
         if time.perf_counter() - last[0] > 30:
             last[0] = time.perf_counter()
             print("[config2] %d games, %.0f s, %d slots alive" % (total, last[0] - t0, e.n_alive), flush=True)
-    ex = eng.run(total, progress=progress)
+    if a.free_running:
+        from yinyang_game_alphazero_amd.self_play import shard_games
+        for k, l in enumerate(eng.lanes):
+            l.begin_run(shard_games(total, k, len(eng.lanes))[0])
+        live = [l for l in eng.lanes if l.n_alive > 0]
+        for l in live:
+            l.enqueue_move()
+        while live:
+            for l in list(live):
+                l.finish_move()
+                if l.n_alive > 0:
+                    l.enqueue_move()
+                else:
+                    live.remove(l)
+            progress(eng)
+        eng.ctx.status()
+        ex = eng.collect()
+    else:
+        ex = eng.run(total, progress=progress)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     c = eng.ctx.status()
     n = int(ex["values"].shape[0])
