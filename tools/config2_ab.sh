@@ -1,3 +1,4 @@
 set -e
-python tools/config2_full.py --reuse 1 --book 8 --out gpurun_out/c2_final_reuse.json 2>&1 | grep wall_s | cut -c1-220
-python tools/config2_full.py --rows 12 --games 1024 --slots 1024 --sims 1600 --single --out gpurun_out/c4_final_reuse.json 2>&1 | grep wall_s | cut -c1-220
+for M in 2 4 8 2; do
+python tools/config2_full.py --single --reuse 1 --book 8 --hint-mult $M --out gpurun_out/c2_hint_$M.json 2>&1 | grep wall_s | cut -c100-200
+done

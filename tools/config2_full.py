@@ -23,9 +23,13 @@ ap.add_argument("--lanes", type=int, default=2, help="HIP streams the slots are 
 ap.add_argument("--cols", type=int, default=0)
 ap.add_argument("--out", default="gpurun_out/config2_full.json")
 ap.add_argument("--split-wg", type=int, default=0, help="override network.G_SPLIT_WG (A/B)")
+ap.add_argument("--hint-mult", type=float, default=0, help="override network.G_HINT_BIG_ONLY (A/B)")
 ap.add_argument("--form", default="auto", choices=["auto", "big"], help="big = the evaluator always launches the large tower form only (A/B)")
 ap.add_argument("--free-running", action="store_true", help="each lane's next move is enqueued as soon as its last one was read back, instead of all lanes starting every move together as SelfPlayLanes.run() does (A/B: how run() was decided)")
 a = ap.parse_args()
+if a.hint_mult:
+    from yinyang_game_alphazero_amd import network as _net
+    _net.G_HINT_BIG_ONLY = a.hint_mult
 if a.form == "big":
     from yinyang_game_alphazero_amd import network as _net
     _real_hint = _net.BatchedEvaluator.rows_hint

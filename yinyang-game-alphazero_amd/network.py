@@ -25,6 +25,8 @@ G_SPLIT_WG = 256                 # live rows <= this many workgroups of the smal
                                  # evaluation-reuse leg at 4096 games (bench.py --split-wg, one box; rows per launch rise from ~12 to ~800 inside a
                                  # search, tools/reuse_rows_hist.py): 192 -> 6 781 positions/s, 256 -> 7 118, 320 -> 7 073, 384 -> 7 054,
                                  # 512 -> 6 990, 640 -> 6 846
+G_HINT_BIG_ONLY = 4                # an owner whose last move averaged >= this many times the split per step launches the large form only
+                                 # (config 2 to completion with the engine's defaults, one box: 2 -> 6 284 / 6 334 positions/s, 4 -> 6 474, 8 -> 6 460)
 G_AUTO_MAX_WG = 2048             # batches up to this many small-form workgroups enqueue both forms, gated on the device-side row count
 HEAD_CHANNELS = 32
 VALUE_HIDDEN = 256
@@ -598,7 +600,7 @@ class BatchedEvaluator:
                     # dropped: an unneeded gated launch is not free under lanes, its empty workgroups queue behind the other
                     # lane's running ones.
                     hint = self._hint.get(static) if static is not True and static is not False else None
-                    if hint is not None and hint >= 2 * self.g_split:
+                    if hint is not None and hint >= G_HINT_BIG_ONLY * self.g_split:
                         feats = tg(self.g_big, (-1, 0x7FFFFFFF), feats)
                     else:
                         feats = tg(self.g_small, (-1, self.g_split), feats)
